@@ -1,0 +1,11 @@
+kreeq validate -f testFiles/random1.fastq.gz -r testFiles/random1.fastq.gz
+embedded
+DBG Summary statistics:
+Total kmers: 172
+Unique kmers: 25
+Distinct kmers: 96
+Missing kmers: 4398046511008
+Total edges: 160
+Missing	Total	QV	Error	k	Method
+0	172	inf	0	21	Merqury
+0	172	inf	0	21	Kreeq

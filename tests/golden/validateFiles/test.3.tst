@@ -1,0 +1,11 @@
+kreeq validate -f testFiles/random1.fasta -r testFiles/random1.fastq testFiles/random2.fastq
+embedded
+DBG Summary statistics:
+Total kmers: 1572
+Unique kmers: 13
+Distinct kmers: 115
+Missing kmers: 4398046510989
+Total edges: 196
+Missing	Total	QV	Error	k	Method
+159	711	19.215	0.0119812	21	Merqury
+159	711	19.215	0.0119812	21	Kreeq

@@ -1,0 +1,135 @@
+"""Shared test helpers: fixture paths, FASTA/FASTQ(.gz) reading, .tst parsing, reference-style text."""
+import gzip
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+INPUTS = os.path.join(GOLDEN, "inputs")
+
+
+def golden_input(name):
+    """maps the reference's 'testFiles/x' to the committed copy"""
+    return os.path.join(INPUTS, os.path.basename(name))
+
+
+def read_fastx(path):
+    """-> [(header, sequence bytes)], FASTA (multi-line) or FASTQ, optionally gzipped.
+    Mirrors the reference loader's behaviour (src/input.cpp:208-286): FASTA sequence text has its
+    newlines removed; FASTQ records are 4 lines."""
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rb") as f:
+        data = f.read()
+    out = []
+    if data[:1] == b">":
+        for rec in data[1:].split(b"\n>"):
+            head, _, seq = rec.partition(b"\n")
+            out.append((head.split(b" ")[0].decode(), seq.replace(b"\n", b"").replace(b"\r", b"")))
+    elif data[:1] == b"@":
+        lines = data.split(b"\n")
+        for i in range(0, len(lines) - 3, 4):
+            if not lines[i].startswith(b"@"):
+                break
+            out.append((lines[i][1:].split(b" ")[0].decode(), lines[i + 1].strip()))
+    else:
+        raise ValueError("not FASTA/FASTQ: " + path)
+    return out
+
+
+def reads_batch(paths):
+    """One read batch: reads separated by a non-ACGT byte."""
+    seqs = []
+    for p in paths:
+        seqs += [s for _, s in read_fastx(p)]
+    return b"\n".join(seqs)
+
+
+def parse_tst(path):
+    lines = open(path).read().split("\n")
+    assert lines[1] == "embedded"
+    exp = lines[2:]
+    while exp and exp[-1] == "":
+        exp.pop()
+    return lines[0].split(), exp
+
+
+def parse_validate_cmd(argv):
+    """['kreeq','validate','-f',asm,'-r',r1,r2..] -> (asm, [reads])"""
+    asm, reads, i = None, [], 2
+    while i < len(argv):
+        if argv[i] == "-f":
+            asm = argv[i + 1]
+            i += 2
+        elif argv[i] == "-r":
+            i += 1
+            while i < len(argv) and not argv[i].startswith("-"):
+                reads.append(argv[i])
+                i += 1
+        else:
+            i += 1
+    return asm, reads
+
+
+def fmt_double(x):
+    """std::cout << double with default precision (6 significant digits, %g)"""
+    return "%g" % x
+
+
+def stats_block(st):
+    """DBG::DBstats text, reference src/graph-builder.cpp:288-293"""
+    return ["DBG Summary statistics:",
+            f"Total kmers: {st['total']}",
+            f"Unique kmers: {st['unique']}",
+            f"Distinct kmers: {st['distinct']}",
+            f"Missing kmers: {st['missing']}",
+            f"Total edges: {st['edges']}"]
+
+
+def qv_block(missing, total, edge_missing, k, error_rate, qv):
+    """reference src/kreeq.cpp:80-104"""
+    rows = ["Missing\tTotal\tQV\tError\tk\tMethod"]
+    for miss, name in ((missing, "Merqury"), (missing + edge_missing, "Kreeq")):
+        rows.append(f"{miss}\t{total}\t{fmt_double(qv(miss, total, k))}\t{fmt_double(error_rate(miss, total, k))}\t{k}\t{name}")
+    return rows
+
+
+def load_db_table(name):
+    """tests/golden/db_tables/<name>.tsv -> structured array (same dtype as oracle ENTRY_DTYPE)"""
+    dt = np.dtype([("key", "<u8"), ("fw", "<u4", 4), ("bw", "<u4", 4), ("cov", "<u4"), ("hc", "<u4")])
+    rows = []
+    for line in open(os.path.join(GOLDEN, "db_tables", name + ".tsv")):
+        if line.startswith("#"):
+            continue
+        v = [int(x) for x in line.split()]
+        rows.append((v[1], v[2:6], v[6:10], v[10], v[11]))
+    return np.array(rows, dtype=dt)
+
+
+def entries_equal(a, b):
+    """logical table equality on (key, fw, bw, cov, hc), both sorted by key"""
+    if len(a) != len(b):
+        return False
+    return all(np.array_equal(a[f], b[f]) for f in ("key", "fw", "bw", "cov", "hc"))
+
+
+def synth_reads(n_reads, read_len, genome_len, seed, err=0.005, n_rate=0.0, sep=b"\n"):
+    """small deterministic synthetic read batch for parity tests (numpy PCG64)."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genome = rng.integers(0, 4, genome_len, dtype=np.uint8)
+    starts = rng.integers(0, genome_len - read_len + 1, n_reads)
+    idx = starts[:, None] + np.arange(read_len)[None, :]
+    codes = genome[idx]
+    strand = rng.integers(0, 2, n_reads).astype(bool)
+    codes[strand] = 3 - codes[strand][:, ::-1]
+    errs = rng.random(codes.shape) < err
+    codes = np.where(errs, (codes + rng.integers(1, 4, codes.shape, dtype=np.uint8)) & 3, codes).astype(np.uint8)
+    chars = acgt[codes]
+    if n_rate > 0:
+        chars = np.where(rng.random(chars.shape) < n_rate, ord("N"), chars).astype(np.uint8)
+    lower = rng.random(chars.shape) < 0.01
+    chars = np.where(lower & (chars != ord("N")), chars | 0x20, chars).astype(np.uint8)
+    out = np.full((n_reads, read_len + len(sep)), sep[0], dtype=np.uint8)
+    out[:, :read_len] = chars
+    return out.tobytes()[:-len(sep)], acgt[genome].tobytes()
