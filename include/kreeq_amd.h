@@ -1,0 +1,175 @@
+/*
+ * kreeq_amd.h -- C ABI of the MI355X-native k-mer count / QV engine (libkreeq_amd.so).
+ *
+ * This is the drop-in boundary for kreeq's hot path.  kreeq has no plugin / FFI interface; the
+ * seams a replacement sits behind are the CRTP hooks gfalibs' Kmap calls on DBG.
+ * Each entry point below names the reference hook it replaces (paths relative to the reference
+ * repository vgl-hub/kreeq @ 2024_08_07).  INTEGRATION.md shows the binding a kreeq maintainer
+ * would add inside those hooks.
+ *
+ * Conventions
+ *   - every function returns 0 (KQ_OK) or a negative kq_status; kq_last_error() returns a
+ *     thread-local message for the last failure on the calling thread; no C++ exception and no
+ *     torch type ever crosses this boundary;
+ *   - one handle per GPU; calls on one handle must be serialised by the caller, different handles
+ *     may be used from different threads / processes concurrently;
+ *   - plain pointers and sizes only.  "host" entry points take host buffers and copy over PCIe;
+ *     the *_dev entry points take device pointers valid on the handle's GPU and are asynchronous
+ *     on the handle's stream (kq_sync() / any host-returning call synchronises);
+ *   - a "read batch" / "sequence" is a byte string of bases; any byte other than ACGTacgt ends
+ *     the current run, so reads inside a batch are separated by one such byte (e.g. '\n' or 'N')
+ *     and k-mers never span it -- exactly the reference's behaviour on a bad base
+ *     (src/graph-builder.cpp:77-91) and gfalibs' splitting of assembly sequences at N.
+ *
+ * There is no CPU fallback: every compute entry point fails with KQ_ERR_NO_DEVICE when no gfx950
+ * device is usable.
+ */
+#ifndef KREEQ_AMD_H
+#define KREEQ_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KQ_ABI_VERSION 1
+
+typedef enum {
+    KQ_OK = 0,
+    KQ_ERR_INVALID = -1,     /* bad argument (k, map_count, null pointer, map range ...) */
+    KQ_ERR_NO_DEVICE = -2,   /* no usable HIP device / kernel image for this GPU */
+    KQ_ERR_HIP = -3,         /* a HIP runtime call failed; message has the HIP error string */
+    KQ_ERR_NOMEM = -4,       /* device or host allocation failed */
+    KQ_ERR_TABLE_FULL = -5,  /* k-mer table (or its high-copy side table) could not grow */
+    KQ_ERR_CAPACITY = -6,    /* caller's output buffer too small (n_out holds the needed size) */
+    KQ_ERR_MISMATCH = -7     /* handles disagree on k / map_count / device */
+} kq_status;
+
+typedef struct kq_handle kq_handle;
+
+/* Logical table entry == one k-mer of the de Bruijn graph with exact counters.
+ * Replaces the value types DBGkmer / DBGkmer32 (include/kreeq.h:20-21, :69-70): hc != 0 marks a
+ * k-mer that the reference keeps in the 32-bit high-copy map (cov >= 255), hc == 0 one whose
+ * counters all fit the 8-bit map.  Counters saturate at 2^32-1 (LARGEST, include/kreeq.h:68). */
+typedef struct {
+    uint64_t key;
+    uint32_t fw[4], bw[4], cov;
+    uint32_t hc;
+} kq_entry;
+
+/* Per-position validation result == DBGbase (include/input.h:4-9). */
+typedef struct {
+    uint32_t fw, bw, cov;
+    uint8_t  isFw;
+    uint8_t  pad[3];
+} kq_dbgbase;
+
+/* Numbers of the "DBG Summary statistics" block (DBG::summary + DBG::DBstats,
+ * src/graph-builder.cpp:240-295), including the ":254/:263" edge-count precedence quirk. */
+typedef struct {
+    uint64_t total;     /* Total kmers    */
+    uint64_t unique;    /* Unique kmers   */
+    uint64_t distinct;  /* Distinct kmers */
+    uint64_t missing;   /* Missing kmers = 4^k - distinct */
+    uint64_t edges;     /* Total edges    */
+} kq_stats;
+
+/* Running totals of one handle (not part of the reference; used for throughput reporting). */
+typedef struct {
+    uint64_t kmers_counted;   /* k-mer instances inserted so far (sum of cov added)          */
+    uint64_t slots_used;      /* occupied table slots == distinct k-mers                      */
+    uint64_t slots_total;     /* table capacity in slots                                      */
+    uint64_t hc_used;         /* occupied high-copy side-table slots                          */
+    uint64_t hc_total;
+    uint64_t table_bytes;     /* HBM bytes held by table + side table                         */
+} kq_info;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+
+/* Replaces the DBG / Kmap constructor (include/kreeq.h:168-177): k = kmerLen (2..32), map_count =
+ * gfalibs mapCount (128 in every .kreeq .index).  capacity_hint = expected distinct k-mers
+ * (0 = small default; the table grows by rehashing when needed). */
+int  kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capacity_hint);
+void kq_destroy(kq_handle* h);
+/* Drop all k-mers, keep the allocation. */
+int  kq_clear(kq_handle* h);
+/* Make the handle enqueue on a caller-owned hipStream_t (NULL = the handle's own stream). */
+int  kq_set_stream(kq_handle* h, void* hip_stream);
+void* kq_get_stream(kq_handle* h);
+int  kq_sync(kq_handle* h);
+int  kq_get_info(kq_handle* h, kq_info* out);
+const char* kq_last_error(void);
+int  kq_abi_version(void);
+/* 1 when a gfx950-capable device is visible to the HIP runtime. */
+int  kq_device_available(void);
+
+/* ---- hot loop 1 + 2: count ---------------------------------------------------------------- */
+
+/* Replaces DBG::hashSequences (src/graph-builder.cpp:34-126) followed by DBG::processBuffers for
+ * every map (:128-223) on one read batch: ASCII -> 2-bit, canonical key, edge byte, insert/RMW of
+ * cov + 8 edge counters.  The key % mapCount disk partition of the reference has no counterpart
+ * here (single table in HBM). */
+int  kq_count_batch(kq_handle* h, const char* bases, uint64_t len);
+int  kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len);
+
+/* Hot loop 1 only (DBG::hashSequences :75-113): the (key, edge byte) records of a batch in
+ * sequence order; edge byte layout = edgeBit (include/kreeq.h:6-18).  *n_out = number of records
+ * (also set on KQ_ERR_CAPACITY).  keys/edges may be NULL to just count. */
+int  kq_emit_records(kq_handle* h, const char* bases, uint64_t len,
+                     uint64_t* keys, uint8_t* edges, uint64_t cap, uint64_t* n_out);
+/* Device variant used to stage the multi-GPU exchange: records are grouped by owner part
+ * (part p owns maps [p*map_count/n_parts, (p+1)*map_count/n_parts) of key % map_count; order
+ * inside a part is unspecified).  d_keys/d_edges need room for len records; part_counts[n_parts]
+ * is a HOST array. Synchronises. */
+int  kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts,
+                             uint64_t* d_keys, uint8_t* d_edges, uint64_t cap,
+                             uint64_t* part_counts);
+
+/* Hot loop 2 only (DBG::processBuffers :160-206) on explicit records. */
+int  kq_insert_records(kq_handle* h, const uint64_t* keys, const uint8_t* edges, uint64_t n);
+int  kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d_edges, uint64_t n);
+
+/* ---- summary ------------------------------------------------------------------------------ */
+
+/* Replaces DBG::summary(m) for all m + DBG::DBstats (src/graph-builder.cpp:240-295). */
+int  kq_summary(kq_handle* h, kq_stats* out);
+/* finalHistogram (src/graph-builder.cpp:274-278; printed by gfalibs printHist): (cov, count)
+ * pairs sorted by cov.  cov/cnt may be NULL to get *n_out only. */
+int  kq_histogram(kq_handle* h, uint64_t* cov, uint64_t* cnt, uint64_t cap, uint64_t* n_out);
+
+/* ---- hot loop 3: assembly lookup + QV counters --------------------------------------------- */
+
+/* Replaces DBG::evaluateSegment (src/kreeq.cpp:110-229) for every segment of one assembly
+ * sequence: the sequence is split into segments at non-ACGT bytes; every k-mer whose map index
+ * key % map_count lies in [map_lo, map_hi) is looked up.  counters[0] += missing,
+ * counters[1] += k-mers evaluated, counters[2] += edge-missing (the three atomics of
+ * include/kreeq.h:152).  per_base (nullable) has `len` entries aligned with `bases`, must be
+ * zero-initialised by the caller before the first map range (generateValidationVector,
+ * src/input.cpp:38-45) and is updated only at evaluated positions. */
+int  kq_lookup_sequence(kq_handle* h, const char* bases, uint64_t len, uint32_t cov_cutoff,
+                        uint16_t map_lo, uint16_t map_hi, kq_dbgbase* per_base,
+                        uint64_t counters[3]);
+/* d_counters: 3 x u64 on the device, accumulated with atomics (zero them first). Asynchronous. */
+int  kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uint32_t cov_cutoff,
+                            uint16_t map_lo, uint16_t map_hi, kq_dbgbase* d_per_base,
+                            uint64_t* d_counters);
+
+/* ---- union / database import-export --------------------------------------------------------- */
+
+/* Replaces DBG::kunion + DBG::mergeSubMaps (src/graph-builder.cpp:297-432): dst += src, exact
+ * saturating sums; both handles must live on the same device. */
+int  kq_merge(kq_handle* dst, kq_handle* src);
+
+/* Replaces phmap_load of <db>/.map.<m>.bin + .map.hc.bin (src/graph-builder.cpp:307-308, gfalibs
+ * loadMapRange): ADDS logical entries to the table (importing two databases == union). */
+int  kq_import(kq_handle* h, const kq_entry* entries, uint64_t n);
+/* Replaces gfalibs dumpMap/dumpHighCopyKmers: logical entries with key % map_count in
+ * [map_lo, map_hi), sorted by key.  out may be NULL to get *n_out only. */
+int  kq_export(kq_handle* h, uint16_t map_lo, uint16_t map_hi, kq_entry* out, uint64_t cap,
+               uint64_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KREEQ_AMD_H */

@@ -1,0 +1,68 @@
+"""In-tree build of the native pieces (no JIT cache: the .so/.bin travel with the repo snapshot).
+
+  kreeq_amd/lib/libkreeq_amd.so   HIP kernels + C ABI (include/kreeq_amd.h), gfx950 only
+  kreeq_amd/bin/kreeq             host CLI clone (validate / union), links the library above
+"""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB = os.path.join(PKG, "lib", "libkreeq_amd.so")
+CLI = os.path.join(PKG, "bin", "kreeq")
+
+HIP_SOURCES = [os.path.join(PKG, "csrc", "kreeq_amd.hip")]
+HIP_DEPS = HIP_SOURCES + [os.path.join(PKG, "csrc", "kq_device.h"), os.path.join(ROOT, "include", "kreeq_amd.h")]
+HOST_DIR = os.path.join(PKG, "host")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU fallback)")
+
+
+def build_lib(force=False, verbose=False):
+    if force or _stale(LIB, HIP_DEPS):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-value",
+               "-o", LIB] + HIP_SOURCES
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def host_sources():
+    if not os.path.isdir(HOST_DIR):
+        return []
+    return sorted(os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith(".cpp"))
+
+
+def build_cli(force=False, verbose=False):
+    srcs = host_sources()
+    if not srcs:
+        return None
+    deps = srcs + [os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith(".h")] + [LIB]
+    if force or _stale(CLI, deps):
+        os.makedirs(os.path.dirname(CLI), exist_ok=True)
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", CLI] + srcs + \
+              ["-L", os.path.dirname(LIB), "-lkreeq_amd", "-lz", "-Wl,-rpath,$ORIGIN/../lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CLI
+
+
+def build_all(force=False, verbose=False):
+    build_lib(force, verbose)
+    build_cli(force, verbose)

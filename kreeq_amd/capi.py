@@ -1,0 +1,231 @@
+"""ctypes binding of the C ABI (include/kreeq_amd.h).  Thin: argument marshalling and error
+translation only -- all compute happens in libkreeq_amd.so on the GPU.  There is no fallback:
+if the library is missing or no gfx950 device is visible, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+ENTRY_DTYPE = np.dtype([("key", "<u8"), ("fw", "<u4", 4), ("bw", "<u4", 4), ("cov", "<u4"), ("hc", "<u4")])
+DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw", "u1"), ("pad", "u1", 3)])
+
+# every symbol include/kreeq_amd.h declares
+SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_get_info", "kq_last_error",
+           "kq_abi_version", "kq_device_available", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
+           "kq_emit_partitioned_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
+           "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_merge", "kq_import", "kq_export"]
+
+
+class KqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"kreeq_amd error {code}: {msg}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("total", C.c_uint64), ("unique", C.c_uint64), ("distinct", C.c_uint64), ("missing", C.c_uint64),
+                ("edges", C.c_uint64)]
+
+
+class Info(C.Structure):
+    _fields_ = [("kmers_counted", C.c_uint64), ("slots_used", C.c_uint64), ("slots_total", C.c_uint64), ("hc_used", C.c_uint64),
+                ("hc_total", C.c_uint64), ("table_bytes", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def _preload_process_hip_runtime():
+    """One process must hold ONE HIP/HSA runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so.7; if /opt/rocm's copy gets loaded first (through this library's NEEDED entry)
+    and torch's afterwards, the second runtime sees no GPU.  So when torch is installed, load its
+    copy first: this library's NEEDED soname then resolves to it, and torch later reuses it."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
+def load():
+    """Loads libkreeq_amd.so (must have been built: __graft_entry__.build() / kreeq_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.LIB):
+        raise KqError(-2, f"{_build.LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the product has no CPU fallback)")
+    _preload_process_hip_runtime()
+    L = C.CDLL(_build.LIB)
+    vp, u64, u32, u16, ci = C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint16, C.c_int
+    L.kq_create.argtypes = [C.POINTER(vp), ci, ci, ci, u64]
+    L.kq_destroy.argtypes = [vp]
+    L.kq_destroy.restype = None
+    L.kq_clear.argtypes = [vp]
+    L.kq_set_stream.argtypes = [vp, vp]
+    L.kq_get_stream.argtypes = [vp]
+    L.kq_get_stream.restype = vp
+    L.kq_sync.argtypes = [vp]
+    L.kq_get_info.argtypes = [vp, C.POINTER(Info)]
+    L.kq_last_error.restype = C.c_char_p
+    L.kq_count_batch.argtypes = [vp, vp, u64]
+    L.kq_count_batch_dev.argtypes = [vp, vp, u64]
+    L.kq_emit_records.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
+    L.kq_emit_partitioned_dev.argtypes = [vp, vp, u64, ci, vp, vp, u64, vp]
+    L.kq_insert_records.argtypes = [vp, vp, vp, u64]
+    L.kq_insert_records_dev.argtypes = [vp, vp, vp, u64]
+    L.kq_summary.argtypes = [vp, C.POINTER(Stats)]
+    L.kq_histogram.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+    L.kq_lookup_sequence.argtypes = [vp, vp, u64, u32, u16, u16, vp, vp]
+    L.kq_lookup_sequence_dev.argtypes = [vp, vp, u64, u32, u16, u16, vp, vp]
+    L.kq_merge.argtypes = [vp, vp]
+    L.kq_import.argtypes = [vp, vp, u64]
+    L.kq_export.argtypes = [vp, u16, u16, vp, u64, C.POINTER(u64)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise KqError(rc, load().kq_last_error().decode(errors="replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_available():
+    return bool(load().kq_device_available())
+
+
+class KreeqDB:
+    """One k-mer database resident on one GPU (mirrors the reference's DBG object for the hot path)."""
+
+    def __init__(self, k=21, map_count=128, device=0, capacity_hint=0):
+        self.k, self.map_count, self.device = k, map_count, device
+        self._h = C.c_void_p()
+        _check(load().kq_create(C.byref(self._h), device, k, map_count, capacity_hint))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().kq_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- stream / state
+    def set_stream(self, hip_stream_ptr):
+        _check(load().kq_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def sync(self):
+        _check(load().kq_sync(self._h))
+
+    def clear(self):
+        _check(load().kq_clear(self._h))
+
+    def info(self):
+        i = Info()
+        _check(load().kq_get_info(self._h, C.byref(i)))
+        return {f: getattr(i, f) for f, _ in Info._fields_}
+
+    # -- count
+    def count_batch(self, bases: bytes):
+        buf = np.frombuffer(bases, dtype=np.uint8)
+        _check(load().kq_count_batch(self._h, _p(buf), len(buf)))
+
+    def count_batch_dev(self, ptr, n):
+        _check(load().kq_count_batch_dev(self._h, C.c_void_p(ptr), n))
+
+    def emit_records(self, bases: bytes):
+        buf = np.frombuffer(bases, dtype=np.uint8)
+        n = C.c_uint64(0)
+        _check(load().kq_emit_records(self._h, _p(buf), len(buf), None, None, 0, C.byref(n)))
+        keys = np.empty(n.value, dtype=np.uint64)
+        edges = np.empty(n.value, dtype=np.uint8)
+        if n.value:
+            _check(load().kq_emit_records(self._h, _p(buf), len(buf), _p(keys), _p(edges), n.value, C.byref(n)))
+        return keys, edges
+
+    def emit_partitioned_dev(self, bases_ptr, n, n_parts, keys_ptr, edges_ptr, cap):
+        counts = np.zeros(n_parts, dtype=np.uint64)
+        _check(load().kq_emit_partitioned_dev(self._h, C.c_void_p(bases_ptr), n, n_parts, C.c_void_p(keys_ptr), C.c_void_p(edges_ptr),
+                                              cap, _p(counts)))
+        return counts
+
+    def insert_records(self, keys, edges):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        edges = np.ascontiguousarray(edges, dtype=np.uint8)
+        assert len(keys) == len(edges)
+        _check(load().kq_insert_records(self._h, _p(keys), _p(edges), len(keys)))
+
+    def insert_records_dev(self, keys_ptr, edges_ptr, n):
+        _check(load().kq_insert_records_dev(self._h, C.c_void_p(keys_ptr), C.c_void_p(edges_ptr), n))
+
+    # -- summary
+    def summary(self, with_hist=False):
+        st = Stats()
+        _check(load().kq_summary(self._h, C.byref(st)))
+        d = {f: getattr(st, f) for f, _ in Stats._fields_}
+        if with_hist:
+            n = C.c_uint64(0)
+            _check(load().kq_histogram(self._h, None, None, 0, C.byref(n)))
+            cov = np.zeros(n.value, dtype=np.uint64)
+            cnt = np.zeros(n.value, dtype=np.uint64)
+            _check(load().kq_histogram(self._h, _p(cov), _p(cnt), n.value, C.byref(n)))
+            d["hist"] = dict(zip(cov.tolist(), cnt.tolist()))
+        return d
+
+    # -- lookup
+    def lookup_sequence(self, bases: bytes, cov_cutoff=0, map_lo=0, map_hi=None, per_base=False, per_base_buf=None):
+        if map_hi is None:
+            map_hi = self.map_count
+        buf = np.frombuffer(bases, dtype=np.uint8)
+        ctr = np.zeros(3, dtype=np.uint64)
+        pb = per_base_buf if per_base_buf is not None else (np.zeros(len(buf), dtype=DBGBASE_DTYPE) if per_base else None)
+        _check(load().kq_lookup_sequence(self._h, _p(buf), len(buf), cov_cutoff, map_lo, map_hi, _p(pb), _p(ctr)))
+        return ctr, pb
+
+    def lookup_sequence_dev(self, bases_ptr, n, counters_ptr, cov_cutoff=0, map_lo=0, map_hi=None, per_base_ptr=None):
+        if map_hi is None:
+            map_hi = self.map_count
+        _check(load().kq_lookup_sequence_dev(self._h, C.c_void_p(bases_ptr), n, cov_cutoff, map_lo, map_hi,
+                                             C.c_void_p(per_base_ptr) if per_base_ptr else None, C.c_void_p(counters_ptr)))
+
+    # -- union / io
+    def merge(self, other):
+        _check(load().kq_merge(self._h, other._h))
+
+    def import_entries(self, entries):
+        entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+        _check(load().kq_import(self._h, _p(entries), len(entries)))
+
+    def export(self, map_lo=0, map_hi=None):
+        if map_hi is None:
+            map_hi = self.map_count
+        n = C.c_uint64(0)
+        _check(load().kq_export(self._h, map_lo, map_hi, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=ENTRY_DTYPE)
+        if n.value:
+            _check(load().kq_export(self._h, map_lo, map_hi, _p(out), n.value, C.byref(n)))
+        return out

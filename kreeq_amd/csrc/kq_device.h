@@ -1,0 +1,320 @@
+// kq_device.h -- device-side building blocks shared by all kernels (gfx950 only).
+//
+// HBM layout (see DESIGN.md "Data layout"):
+//   main table   : n_regions x REGION_SLOTS slots of 24 B  { u64 key; u64 edges8; u64 cov }
+//                  key   = canonical 2-bit k-mer (EMPTY = ~0, never a canonical key)
+//                  edges8= 8 packed u8 counters, byte e = edge e of include/kreeq.h:6-18
+//                          (e 0..3 = fw[A,C,G,T], 4..7 = bw[A,C,G,T]); only the first 254
+//                          instances of a k-mer add here, so no byte ever carries
+//                  cov   = exact instance count (u64; clamped to 2^32-1 when read out)
+//                  a key lives in region mulhi(mix(key), n_regions) and is probed linearly
+//                  INSIDE that region only (regions are independent little tables: this is what
+//                  lets a workgroup own a region exclusively in the partitioned count path)
+//   high-copy    : power-of-two open-addressing table of 72 B { u64 key; u64 cnt[8] }: edge
+//                  counts of instances number 255.. of a k-mer (the reference's maps32 tier)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kq {
+
+constexpr uint64_t EMPTY_KEY = ~0ull;
+constexpr uint32_t LARGEST = 4294967295u;      // include/kreeq.h:68
+constexpr uint32_t LOW_TIER_MAX = 254;         // src/graph-builder.cpp:166: the 255th instance overflows
+constexpr int REGION_SHIFT = 12;
+constexpr uint32_t REGION_SLOTS = 1u << REGION_SHIFT;   // 4096 slots x 24 B = 96 KiB (fits LDS)
+
+struct Slot { uint64_t key, edges8, cov; };
+struct HcSlot { uint64_t key; uint64_t cnt[8]; };
+
+// device-resident state the host reads back after a sync
+struct DevState {
+    unsigned long long slots_used;    // occupied main slots
+    unsigned long long hc_used;       // occupied high-copy slots
+    unsigned long long kmers_added;   // sum of cov added
+    unsigned int err_table_full;      // a region had no free slot
+    unsigned int err_hc_full;
+    unsigned int pad[2];
+};
+
+struct TableView {
+    Slot* slots;
+    uint64_t n_regions;
+    HcSlot* hc;
+    uint64_t hc_mask;       // capacity - 1
+    DevState* st;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t h) {
+    h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
+    h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 33;
+    return h;
+}
+
+// reverse complement of a 2-bit packed k-mer, first base in the low bits:
+// rv = sum (3-b[c]) 4^(k-1-c)
+__device__ __forceinline__ uint64_t revcomp2(uint64_t fw, int k) {
+    uint64_t x = __builtin_bitreverse64(~fw);
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    return x >> (64 - 2 * k);
+}
+
+// edge index pair -> packed u8x8 increment.  Mirrors src/graph-builder.cpp:98-110.
+// prev/next = base codes 0..3, or 4 when the neighbour is not an ACGT base of the same run.
+__device__ __forceinline__ uint64_t edge_pack(bool is_fw, uint32_t prev, uint32_t next) {
+    uint64_t p = 0;
+    if (is_fw) {
+        if (next < 4) p |= 1ull << (8 * next);
+        if (prev < 4) p |= 1ull << (8 * (4 + prev));
+    } else {
+        if (prev < 4) p |= 1ull << (8 * (3 - prev));
+        if (next < 4) p |= 1ull << (8 * (4 + 3 - next));
+    }
+    return p;
+}
+// packed increment <-> reference edge byte (bit 7-e, include/kreeq.h:10-16)
+__device__ __forceinline__ uint8_t pack_to_edge_byte(uint64_t p) {
+    uint32_t b = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b |= (uint32_t)((p >> (8 * e)) & 1) << (7 - e);
+    return (uint8_t)b;
+}
+__device__ __forceinline__ uint64_t edge_byte_to_pack(uint32_t b) {
+    uint64_t p = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p |= (uint64_t)((b >> (7 - e)) & 1) << (8 * e);
+    return p;
+}
+
+__device__ __forceinline__ uint64_t ld_relaxed(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- main table ------------------------------------------------------------------------------
+__device__ __forceinline__ Slot* region_of(const TableView& t, uint64_t h) {
+    return t.slots + (__umul64hi(h, t.n_regions) << REGION_SHIFT);
+}
+
+// find-or-insert; returns nullptr when the region is full. *inserted = 1 for a new key.
+__device__ __forceinline__ Slot* table_upsert(const TableView& t, uint64_t key, uint32_t* inserted) {
+    const uint64_t h = mix64(key);
+    Slot* base = region_of(t, h);
+    uint32_t off = (uint32_t)h & (REGION_SLOTS - 1);
+    for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
+        Slot* s = base + ((off + probe) & (REGION_SLOTS - 1));
+        uint64_t cur = ld_relaxed(&s->key);
+        if (cur == EMPTY_KEY) {
+            cur = atomicCAS((unsigned long long*)&s->key, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (cur == EMPTY_KEY) { *inserted = 1; return s; }
+        }
+        if (cur == key) return s;
+    }
+    return nullptr;
+}
+
+__device__ __forceinline__ const Slot* table_find(const TableView& t, uint64_t key) {
+    const uint64_t h = mix64(key);
+    const Slot* base = region_of(t, h);
+    uint32_t off = (uint32_t)h & (REGION_SLOTS - 1);
+    for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
+        const Slot* s = base + ((off + probe) & (REGION_SLOTS - 1));
+        uint64_t cur = s->key;
+        if (cur == key) return s;
+        if (cur == EMPTY_KEY) return nullptr;
+    }
+    return nullptr;
+}
+
+// ---- high-copy side table ----------------------------------------------------------------------
+__device__ __forceinline__ HcSlot* hc_upsert(const TableView& t, uint64_t key) {
+    uint64_t i = mix64(key ^ 0x9E3779B97F4A7C15ull) & t.hc_mask;
+    for (uint64_t probe = 0; probe <= t.hc_mask; ++probe, i = (i + 1) & t.hc_mask) {
+        HcSlot* s = t.hc + i;
+        uint64_t cur = ld_relaxed(&s->key);
+        if (cur == EMPTY_KEY) {
+            cur = atomicCAS((unsigned long long*)&s->key, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (cur == EMPTY_KEY) { atomicAdd(&t.st->hc_used, 1ull); return s; }
+        }
+        if (cur == key) return s;
+    }
+    return nullptr;
+}
+__device__ __forceinline__ const HcSlot* hc_find(const TableView& t, uint64_t key) {
+    uint64_t i = mix64(key ^ 0x9E3779B97F4A7C15ull) & t.hc_mask;
+    for (uint64_t probe = 0; probe <= t.hc_mask; ++probe, i = (i + 1) & t.hc_mask) {
+        const HcSlot* s = t.hc + i;
+        uint64_t cur = s->key;
+        if (cur == key) return s;
+        if (cur == EMPTY_KEY) return nullptr;
+    }
+    return nullptr;
+}
+
+// Add `cov` instances of `key` whose edge counts are e[0..7] (each <= cov).
+// Two-tier rule (restates src/graph-builder.cpp:165-205 order-independently): instances that keep
+// the k-mer's total <= 254 add to the packed u8 counters, everything else to the high-copy entry.
+// Because every edge counter <= cov, no u8 lane can exceed 254, and low + high is the exact sum.
+__device__ __forceinline__ bool table_add(const TableView& t, uint64_t key, uint64_t cov, uint64_t pack8,
+                                          const uint32_t* wide /*8 counters or nullptr*/, uint32_t* inserted) {
+    Slot* s = table_upsert(t, key, inserted);
+    if (!s) { atomicOr(&t.st->err_table_full, 1u); return false; }
+    uint64_t old = atomicAdd((unsigned long long*)&s->cov, (unsigned long long)cov);
+    if (old + cov <= LOW_TIER_MAX) {
+        if (pack8) atomicAdd((unsigned long long*)&s->edges8, (unsigned long long)pack8);
+        return true;
+    }
+    bool any = wide ? true : (pack8 != 0);
+    if (!any) return true;
+    HcSlot* hs = hc_upsert(t, key);
+    if (!hs) { atomicOr(&t.st->err_hc_full, 1u); return false; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        uint64_t v = wide ? (uint64_t)wide[e] : ((pack8 >> (8 * e)) & 0xFF);
+        if (v) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)v);
+    }
+    return true;
+}
+
+// logical (reference-visible) value of a slot: counters clamped to LARGEST
+struct Logical { uint32_t e[8]; uint32_t cov; };
+__device__ __forceinline__ Logical slot_logical(const TableView& t, const Slot* s) {
+    Logical L;
+    uint64_t cov = s->cov, e8 = s->edges8;
+    L.cov = cov > LARGEST ? LARGEST : (uint32_t)cov;
+    const HcSlot* hs = (cov > LOW_TIER_MAX) ? hc_find(t, s->key) : nullptr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        uint64_t v = (e8 >> (8 * e)) & 0xFF;
+        if (hs) v += hs->cnt[e];
+        L.e[e] = v > LARGEST ? LARGEST : (uint32_t)v;
+    }
+    return L;
+}
+
+// ---- sequence tile scanner ---------------------------------------------------------------------
+// One workgroup (256 threads) walks tiles of TILE_STARTS k-mer start positions.  Per tile it loads
+// a 4096-byte window (16 B per lane, coalesced), converts it to a 2-bit code stream + an
+// "invalid base" bit stream in LDS, and every lane then rolls through 16 consecutive starts in
+// registers.  f(pos, fw, prev, next) is called for every start whose k bases are all ACGT;
+// prev/next are the neighbouring base codes or 4 when outside the run.
+constexpr int TILE_THREADS = 256;
+constexpr int TILE_STARTS = 4032;          // 252 lanes x 16 starts; window = 4032 + 16 + 48 bytes
+
+__device__ __forceinline__ void convert16(const uint4& v, bool all_in, int64_t g, int64_t lo_valid, int64_t hi_valid,
+                                          uint32_t& codes, uint32_t& inv) {
+    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+    codes = 0; inv = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t x = w[i];
+        uint32_t y = ((x >> 1) ^ (x >> 2)) & 0x03030303u;              // A,C,G,T -> 0,1,2,3 (case-blind)
+        uint32_t c4 = (y | (y >> 6) | (y >> 12) | (y >> 18)) & 0xFFu;
+        codes |= c4 << (8 * i);
+        uint32_t u = x & 0xDFDFDFDFu;                                   // upper-case
+        uint32_t ok = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint32_t ch = (u >> (8 * b)) & 0xFFu;
+            uint32_t idx = ch - 0x41u;                                  // 'A'
+            uint32_t good = (idx < 20u) ? ((0x80045u >> idx) & 1u) : 0u; // A=0 C=2 G=6 T=19
+            ok |= good << b;
+        }
+        inv |= ((~ok) & 0xFu) << (4 * i);
+    }
+    if (!all_in) {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            int64_t p = g + b;
+            if (p < lo_valid || p >= hi_valid) inv |= 1u << b;
+        }
+    }
+}
+
+// loads + converts one tile's 4096-byte window into LDS (ends with a barrier)
+__device__ __forceinline__ void tile_load(const uint8_t* __restrict__ ab, int64_t lo_valid, int64_t hi_valid, uint64_t tile,
+                                          uint32_t* s_codes, uint32_t* s_inv) {
+    const int tid = threadIdx.x;
+    const int64_t g = (int64_t)(tile * TILE_STARTS) - 16 + 16 * tid;
+    uint32_t codes = 0, inv = 0xFFFFu;
+    if (g + 16 > lo_valid && g < hi_valid) {
+        uint4 v = *reinterpret_cast<const uint4*>(ab + g);
+        bool all_in = (g >= lo_valid) && (g + 16 <= hi_valid);
+        convert16(v, all_in, g, lo_valid, hi_valid, codes, inv);
+    }
+    s_codes[tid] = codes;
+    s_inv[tid] = inv;
+    __syncthreads();
+}
+
+// this lane's 16 consecutive starts of the loaded tile; f(pos, fw, prev, next) per valid k-mer
+template <class F>
+__device__ __forceinline__ void tile_lane_scan(const uint32_t* s_codes, const uint32_t* s_inv, int64_t lo_valid, uint64_t tile,
+                                               int k, F&& f) {
+    const int tid = threadIdx.x;
+    if (tid >= TILE_STARTS / 16) return;
+    const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+    const uint64_t wmask = (1ull << k) - 1;
+    const uint32_t c0 = s_codes[tid], c1 = s_codes[tid + 1], c2 = s_codes[tid + 2], c3 = s_codes[tid + 3];
+    const uint32_t m0 = s_inv[tid];
+    const uint64_t ms = (uint64_t)s_inv[tid + 1] | ((uint64_t)s_inv[tid + 2] << 16) | ((uint64_t)s_inv[tid + 3] << 32);
+    const uint64_t lo = (uint64_t)c1 | ((uint64_t)c2 << 32);
+    const uint64_t hi = (uint64_t)c3;
+    uint32_t prev = (m0 >> 15) ? 4u : (c0 >> 30);
+    const int64_t p0 = (int64_t)(tile * TILE_STARTS) + 16 * tid - lo_valid;   // caller position of start 0
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t fw = ((i == 0) ? lo : ((lo >> (2 * i)) | (hi << (64 - 2 * i)))) & kmask;
+        const bool valid = ((ms >> i) & wmask) == 0;
+        if (valid) {
+            const int np = i + k;                                            // 2..47
+            uint32_t next = (np < 32) ? (uint32_t)(lo >> (2 * np)) & 3u : (uint32_t)(hi >> (2 * (np - 32))) & 3u;
+            if ((ms >> np) & 1) next = 4u;
+            f((uint64_t)(p0 + i), fw, prev, next);
+        }
+        prev = ((ms >> i) & 1) ? 4u : ((uint32_t)(lo >> (2 * i)) & 3u);
+    }
+}
+
+// number of valid k-mer starts among this lane's 16
+__device__ __forceinline__ uint32_t tile_lane_count(const uint32_t* s_inv, int k) {
+    const int tid = threadIdx.x;
+    if (tid >= TILE_STARTS / 16) return 0;
+    const uint64_t wmask = (1ull << k) - 1;
+    const uint64_t ms = (uint64_t)s_inv[tid + 1] | ((uint64_t)s_inv[tid + 2] << 16) | ((uint64_t)s_inv[tid + 3] << 32);
+    uint32_t n = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) n += (((ms >> i) & wmask) == 0);
+    return n;
+}
+
+inline __host__ __device__ uint64_t n_tiles_of(uint64_t lead, uint64_t len) { return (lead + len + TILE_STARTS - 1) / TILE_STARTS; }
+
+template <class F>
+__device__ __forceinline__ void scan_tiles(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k, F&& f) {
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        tile_lane_scan(s_codes, s_inv, lo_valid, tile, k, f);
+        __syncthreads();
+    }
+}
+
+// block-wide sum of per-thread u64, result valid in thread 0
+__device__ __forceinline__ uint64_t block_sum(uint64_t v) {
+    __shared__ unsigned long long s_acc;
+    if (threadIdx.x == 0) s_acc = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_acc, (unsigned long long)v);
+    __syncthreads();
+    uint64_t r = s_acc;
+    __syncthreads();
+    return r;
+}
+
+}  // namespace kq

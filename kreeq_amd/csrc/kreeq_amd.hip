@@ -1,0 +1,922 @@
+// kreeq_amd.hip -- HIP kernels + C ABI (include/kreeq_amd.h) of the MI355X-native kreeq hot path.
+// gfx950 only; no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/kreeq_amd.h"
+#include "kq_device.h"
+
+using namespace kq;
+
+// ================================================================================================
+// kernels
+// ================================================================================================
+
+// K1+K2 fused: hashSequences (src/graph-builder.cpp:75-113) + processBuffers (:160-206) without
+// materialising the 9-byte records: 1 B/base streamed in, random RMW on the table.
+__global__ __launch_bounds__(TILE_THREADS) void k_count_direct(TableView t, const uint8_t* __restrict__ ab,
+                                                                uint64_t lead, uint64_t len, int k) {
+    uint32_t n_new = 0;
+    uint64_t n_kmers = 0;
+    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint32_t prev, uint32_t next) {
+        const uint64_t rv = revcomp2(fw, k);
+        const bool is_fw = fw < rv;
+        const uint64_t key = is_fw ? fw : rv;
+        uint32_t ins = 0;
+        if (table_add(t, key, 1, edge_pack(is_fw, prev, next), nullptr, &ins)) ++n_kmers;
+        n_new += ins;
+    });
+    uint64_t a = block_sum(n_new), b = block_sum(n_kmers);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&t.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&t.st->kmers_added, (unsigned long long)b);
+    }
+}
+
+// K1 pass A: number of k-mers per tile (so that pass B can write in sequence order)
+__global__ __launch_bounds__(TILE_THREADS) void k_emit_count(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len,
+                                                              int k, unsigned long long* tile_counts) {
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        uint64_t total = block_sum(tile_lane_count(s_inv, k));
+        if (threadIdx.x == 0) tile_counts[tile] = total;
+    }
+}
+
+// exclusive scan of tile counts (single workgroup; n_tiles is len/4032, i.e. small)
+__global__ __launch_bounds__(1024) void k_exclusive_scan(unsigned long long* a, uint64_t n, unsigned long long* total) {
+    __shared__ unsigned long long s_part[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t lo = (uint64_t)tid * per, hi = lo + per < n ? lo + per : n;
+    unsigned long long sum = 0;
+    for (uint64_t i = lo; i < hi; ++i) sum += a[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; ++i) { unsigned long long v = s_part[i]; s_part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long run = s_part[tid];
+    for (uint64_t i = lo; i < hi; ++i) { unsigned long long v = a[i]; a[i] = run; run += v; }
+}
+
+// K1 pass B: write (key, edge byte) records in sequence order at tile_offsets[tile] + rank in tile
+__global__ __launch_bounds__(TILE_THREADS) void k_emit_write(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+                                                              const unsigned long long* tile_offsets,
+                                                              uint64_t* keys, uint8_t* edges, uint64_t cap) {
+    __shared__ uint32_t s_wave[TILE_THREADS / 64];
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    const int tid = threadIdx.x;
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        const uint32_t mine = tile_lane_count(s_inv, k);
+        // exclusive prefix of `mine` over the workgroup: wave scan + wave totals
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t n = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += n; }
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) wave_base += s_wave[w];
+        uint64_t out = tile_offsets[tile] + wave_base + (incl - mine);
+        tile_lane_scan(s_codes, s_inv, lo_valid, tile, k, [&](uint64_t, uint64_t fw, uint32_t prev, uint32_t next) {
+            const uint64_t rv = revcomp2(fw, k);
+            const bool is_fw = fw < rv;
+            if (out < cap) {
+                keys[out] = is_fw ? fw : rv;
+                edges[out] = pack_to_edge_byte(edge_pack(is_fw, prev, next));
+            }
+            ++out;
+        });
+        __syncthreads();
+    }
+}
+
+// K1 for the multi-GPU exchange: pass A histogram of owner parts, pass B scatter by part.
+__device__ __forceinline__ uint32_t owner_part(uint64_t key, uint32_t map_count, uint32_t n_parts) {
+    uint32_t m = (uint32_t)(key % map_count);            // src/graph-builder.cpp:95
+    return (uint32_t)(((uint64_t)m * n_parts) / map_count);
+}
+__global__ __launch_bounds__(TILE_THREADS) void k_part_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+                                                             uint32_t map_count, uint32_t n_parts, unsigned long long* part_counts) {
+    extern __shared__ unsigned long long s_hist[];
+    for (uint32_t i = threadIdx.x; i < n_parts; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint32_t, uint32_t) {
+        const uint64_t rv = revcomp2(fw, k);
+        atomicAdd(&s_hist[owner_part(fw < rv ? fw : rv, map_count, n_parts)], 1ull);
+    });
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_parts; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&part_counts[i], s_hist[i]);
+}
+__global__ __launch_bounds__(TILE_THREADS) void k_part_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+                                                                uint32_t map_count, uint32_t n_parts, unsigned long long* part_cursor,
+                                                                uint64_t* keys, uint8_t* edges, uint64_t cap) {
+    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint32_t prev, uint32_t next) {
+        const uint64_t rv = revcomp2(fw, k);
+        const bool is_fw = fw < rv;
+        const uint64_t key = is_fw ? fw : rv;
+        uint64_t o = atomicAdd(&part_cursor[owner_part(key, map_count, n_parts)], 1ull);
+        if (o < cap) { keys[o] = key; edges[o] = pack_to_edge_byte(edge_pack(is_fw, prev, next)); }
+    });
+}
+
+// K2 on explicit records: processBuffers :160-206
+__global__ __launch_bounds__(256) void k_insert_records(TableView t, const uint64_t* __restrict__ keys,
+                                                         const uint8_t* __restrict__ edges, uint64_t n) {
+    uint32_t n_new = 0;
+    uint64_t n_ok = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t ins = 0;
+        if (table_add(t, keys[i], 1, edge_byte_to_pack(edges[i]), nullptr, &ins)) ++n_ok;
+        n_new += ins;
+    }
+    uint64_t a = block_sum(n_new), b = block_sum(n_ok);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&t.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&t.st->kmers_added, (unsigned long long)b);
+    }
+}
+
+// import / union: add logical entries (kunion + mergeSubMaps, src/graph-builder.cpp:297-432)
+__device__ __forceinline__ void add_logical(const TableView& t, uint64_t key, const uint32_t* e, uint32_t cov,
+                                            uint32_t& n_new, uint64_t& n_cov) {
+    uint64_t pack = 0;
+    bool fits = cov <= LOW_TIER_MAX;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { if (e[i] > LOW_TIER_MAX) fits = false; pack |= (uint64_t)(e[i] & 0xFF) << (8 * i); }
+    uint32_t ins = 0;
+    // when the entry itself is beyond the low tier, table_add routes all of it to the wide counters
+    if (table_add(t, key, cov, fits ? pack : 0, fits ? nullptr : e, &ins)) n_cov += cov;
+    n_new += ins;
+}
+__global__ __launch_bounds__(256) void k_import(TableView t, const kq_entry* __restrict__ in, uint64_t n) {
+    uint32_t n_new = 0;
+    uint64_t n_cov = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t e[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { e[w] = in[i].fw[w]; e[4 + w] = in[i].bw[w]; }
+        add_logical(t, in[i].key, e, in[i].cov, n_new, n_cov);
+    }
+    uint64_t a = block_sum(n_new), b = block_sum(n_cov);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&t.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&t.st->kmers_added, (unsigned long long)b);
+    }
+}
+// K4: dst += src (both on this device)
+__global__ __launch_bounds__(256) void k_merge(TableView dst, TableView src) {
+    uint32_t n_new = 0;
+    uint64_t n_cov = 0;
+    const uint64_t n = src.n_regions << REGION_SHIFT;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Slot* s = src.slots + i;
+        if (s->key == EMPTY_KEY) continue;
+        Logical L = slot_logical(src, s);
+        add_logical(dst, s->key, L.e, L.cov, n_new, n_cov);
+    }
+    uint64_t a = block_sum(n_new), b = block_sum(n_cov);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&dst.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&dst.st->kmers_added, (unsigned long long)b);
+    }
+}
+// rehash into a bigger table (growth): exact move of physical state
+__global__ __launch_bounds__(256) void k_rehash(TableView dst, const Slot* __restrict__ old, uint64_t n_old) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Slot s = old[i];
+        if (s.key == EMPTY_KEY) continue;
+        uint32_t ins = 0;
+        Slot* d = table_upsert(dst, s.key, &ins);
+        if (!d) { atomicOr(&dst.st->err_table_full, 1u); continue; }
+        d->edges8 = s.edges8;     // unique key per thread: plain stores
+        d->cov = s.cov;
+    }
+}
+__global__ __launch_bounds__(256) void k_rehash_hc(TableView dst, const HcSlot* __restrict__ old, uint64_t n_old) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (old[i].key == EMPTY_KEY) continue;
+        HcSlot* d = hc_upsert(dst, old[i].key);
+        if (!d) { atomicOr(&dst.st->err_hc_full, 1u); continue; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d->cnt[e] = old[i].cnt[e];
+    }
+}
+__global__ void k_fill_keys(uint64_t* p, uint64_t stride_words, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i * stride_words] = EMPTY_KEY;
+}
+
+// K5: summary (src/graph-builder.cpp:240-282).  hist_small[c] for cov < HIST_SMALL; rarer larger
+// coverages are appended to (big_cov, n_big) and folded on the host.
+constexpr uint32_t HIST_SMALL = 4096;
+struct SummaryOut {
+    unsigned long long total, uniq, distinct, edges, n_big, big_cap;
+};
+__global__ __launch_bounds__(256) void k_summary(TableView t, SummaryOut* out, unsigned long long* hist_small,
+                                                  uint32_t* big_cov) {
+    __shared__ uint32_t s_hist[HIST_SMALL];
+    for (uint32_t i = threadIdx.x; i < HIST_SMALL; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    uint64_t total = 0, uniq = 0, distinct = 0, edges = 0;
+    const uint64_t n = t.n_regions << REGION_SHIFT;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Slot* s = t.slots + i;
+        if (s->key == EMPTY_KEY) continue;
+        Logical L = slot_logical(t, s);
+        if (L.cov == 0) continue;                 // cannot happen (a key is inserted with cov >= 1)
+        uniq += (L.cov == 1);                     // :250
+#pragma unroll
+        for (int w = 0; w < 4; ++w)               // :254 / :263 -> fw>0 ? 1 : (bw>0 ? 1 : 0)
+            edges += (L.e[w] > 0) ? 1 : ((L.e[4 + w] > 0) ? 1 : 0);
+        ++distinct;
+        total += L.cov;                           // :274-278 (tot += cov * count)
+        if (L.cov < HIST_SMALL) atomicAdd(&s_hist[L.cov], 1u);
+        else {
+            unsigned long long o = atomicAdd(&out->n_big, 1ull);
+            if (o < out->big_cap) big_cov[o] = L.cov;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HIST_SMALL; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&hist_small[i], (unsigned long long)s_hist[i]);
+    uint64_t a = block_sum(total), b = block_sum(uniq), c = block_sum(distinct), d = block_sum(edges);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&out->total, (unsigned long long)a);
+        if (b) atomicAdd(&out->uniq, (unsigned long long)b);
+        if (c) atomicAdd(&out->distinct, (unsigned long long)c);
+        if (d) atomicAdd(&out->edges, (unsigned long long)d);
+    }
+}
+
+// export: logical entries of maps [lo, hi)
+__global__ __launch_bounds__(256) void k_export(TableView t, uint32_t map_count, uint32_t lo, uint32_t hi,
+                                                 kq_entry* out, uint64_t cap, unsigned long long* n_out) {
+    const uint64_t n = t.n_regions << REGION_SHIFT;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Slot* s = t.slots + i;
+        const uint64_t key = s->key;
+        if (key == EMPTY_KEY) continue;
+        const uint32_t m = (uint32_t)(key % map_count);
+        if (m < lo || m >= hi) continue;
+        unsigned long long o = atomicAdd(n_out, 1ull);
+        if (out && o < cap) {
+            Logical L = slot_logical(t, s);
+            kq_entry e;
+            e.key = key;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { e.fw[w] = L.e[w]; e.bw[w] = L.e[4 + w]; }
+            e.cov = L.cov;
+            e.hc = L.cov > LOW_TIER_MAX;          // in maps32 iff total cov >= 255
+            out[o] = e;
+        }
+    }
+}
+
+// K3: evaluateSegment (src/kreeq.cpp:143-219) over a whole sequence (segments = ACGT runs)
+__global__ __launch_bounds__(TILE_THREADS) void k_lookup(TableView t, const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len,
+                                                          int k, uint32_t map_count, uint32_t map_lo, uint32_t map_hi,
+                                                          uint32_t cov_cutoff, kq_dbgbase* per_base, unsigned long long* counters) {
+    uint64_t missing = 0, total = 0, edge_missing = 0;
+    scan_tiles(ab, lead, len, k, [&](uint64_t pos, uint64_t fw, uint32_t prev, uint32_t next) {
+        const uint64_t rv = revcomp2(fw, k);
+        const bool is_fw = fw < rv;                                        // :145
+        const uint64_t key = is_fw ? fw : rv;
+        const uint32_t m = (uint32_t)(key % map_count);                    // :146
+        if (m < map_lo || m >= map_hi) return;                             // :150
+        kq_dbgbase b;
+        if (per_base) b = per_base[pos]; else { b.fw = b.bw = b.cov = 0; b.isFw = 0; b.pad[0] = b.pad[1] = b.pad[2] = 0; }
+        Logical L;
+        const Slot* s = table_find(t, key);                                // :153
+        if (s) {
+            L = slot_logical(t, s);                                        // :156-166 (8-bit or 32-bit tier)
+            b.cov = L.cov; b.isFw = is_fw;                                 // :168-169
+        }
+        if (b.cov == 0) ++missing;                                         // :172
+        else if (b.cov < cov_cutoff) ++missing;                            // :174
+        else {
+            if (!s) { for (int e = 0; e < 8; ++e) L.e[e] = 0; }            // stale per_base cov, khmer default-constructed
+            bool no_left = false, no_right = false;
+            if (b.isFw) {                                                  // :178-193
+                if (next < 4) { uint32_t v = L.e[next]; if (v) b.fw = v; else no_right = true; }
+                if (prev < 4) { uint32_t v = L.e[4 + prev]; if (v) b.bw = v; else no_left = true; }
+            } else {                                                       // :194-210
+                if (prev < 4) { uint32_t v = L.e[3 - prev]; if (v) b.fw = v; else no_left = true; }
+                if (next < 4) { uint32_t v = L.e[4 + 3 - next]; if (v) b.bw = v; else no_right = true; }
+            }
+            if (no_left && no_right) ++edge_missing;                       // :211
+        }
+        if (per_base) per_base[pos] = b;
+        ++total;                                                           // :216
+    });
+    uint64_t a = block_sum(missing), b = block_sum(total), c = block_sum(edge_missing);
+    if (threadIdx.x == 0) {                                                // :223-225
+        if (a) atomicAdd(&counters[0], (unsigned long long)a);
+        if (b) atomicAdd(&counters[1], (unsigned long long)b);
+        if (c) atomicAdd(&counters[2], (unsigned long long)c);
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPC(expr)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(e_ == hipErrorOutOfMemory ? KQ_ERR_NOMEM : KQ_ERR_HIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                  \
+    } while (0)
+
+struct kq_handle {
+    int device = 0, k = 0, map_count = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int n_cu = 256;
+    Slot* slots = nullptr;
+    uint64_t n_regions = 0;
+    HcSlot* hc = nullptr;
+    uint64_t hc_cap = 0;
+    DevState* st = nullptr;          // device
+    DevState* st_host = nullptr;     // pinned mirror
+    // scratch (grown on demand)
+    void* scratch = nullptr; size_t scratch_bytes = 0;
+    void* stage = nullptr; size_t stage_bytes = 0;     // device staging for host-buffer entry points
+    uint64_t kmers_bound = 0;        // upper bound of instances inserted (sizing the side table)
+    uint64_t used_bound = 0;         // upper bound of occupied slots (skips the state read-back)
+
+    TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; return v; }
+    uint64_t n_slots() const { return n_regions << REGION_SHIFT; }
+};
+
+static int grid_for(const kq_handle* h, uint64_t work_items, int per_block) {
+    uint64_t blocks = (work_items + per_block - 1) / per_block;
+    uint64_t cap = (uint64_t)h->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+static int ensure_buf(void** p, size_t* have, size_t need) {
+    if (*have >= need) return KQ_OK;
+    if (*p) { HIPC(hipFree(*p)); *p = nullptr; *have = 0; }
+    size_t sz = need + need / 4 + 4096;
+    HIPC(hipMalloc(p, sz));
+    *have = sz;
+    return KQ_OK;
+}
+
+static int alloc_main(kq_handle* h, uint64_t n_regions, Slot** out) {
+    Slot* p = nullptr;
+    size_t bytes = (size_t)(n_regions << REGION_SHIFT) * sizeof(Slot);
+    HIPC(hipMalloc((void**)&p, bytes));
+    hipError_t e = hipMemsetAsync(p, 0, bytes, h->stream);
+    if (e != hipSuccess) { hipFree(p); return fail(KQ_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    uint64_t n = n_regions << REGION_SHIFT;
+    hipLaunchKernelGGL(k_fill_keys, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, (uint64_t*)p, (uint64_t)3, n);
+    *out = p;
+    return KQ_OK;
+}
+static int alloc_hc(kq_handle* h, uint64_t cap, HcSlot** out) {
+    HcSlot* p = nullptr;
+    size_t bytes = (size_t)cap * sizeof(HcSlot);
+    HIPC(hipMalloc((void**)&p, bytes));
+    hipError_t e = hipMemsetAsync(p, 0, bytes, h->stream);
+    if (e != hipSuccess) { hipFree(p); return fail(KQ_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    hipLaunchKernelGGL(k_fill_keys, dim3(grid_for(h, cap, 256)), dim3(256), 0, h->stream, (uint64_t*)p, (uint64_t)9, cap);
+    *out = p;
+    return KQ_OK;
+}
+
+static int read_state(kq_handle* h) {
+    HIPC(hipMemcpyAsync(h->st_host, h->st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    return KQ_OK;
+}
+static int check_errors(kq_handle* h) {
+    int rc = read_state(h);
+    if (rc) return rc;
+    if (h->st_host->err_table_full) return fail(KQ_ERR_TABLE_FULL, "k-mer table region overflow (slots %llu / %llu)",
+                                                 (unsigned long long)h->st_host->slots_used, (unsigned long long)h->n_slots());
+    if (h->st_host->err_hc_full) return fail(KQ_ERR_TABLE_FULL, "high-copy side table overflow (%llu / %llu)",
+                                              (unsigned long long)h->st_host->hc_used, (unsigned long long)h->hc_cap);
+    return KQ_OK;
+}
+
+// grow (rehash) so that `extra` more distinct k-mers fit at load <= 0.85, and the side table can
+// take every k-mer that may reach cov >= 255 after `extra_instances` more instances.
+static int reserve(kq_handle* h, uint64_t extra, uint64_t extra_instances) {
+    // fast path without a device round trip: host-side upper bounds say everything fits
+    {
+        const uint64_t need = (uint64_t)((double)(h->used_bound + extra) / 0.85) + REGION_SLOTS;
+        const uint64_t inst = h->kmers_bound + extra_instances;
+        if (need <= h->n_slots() && inst / 255 + 1 <= (1ull << 23) && 2 * (inst / 255 + 1) <= h->hc_cap) {
+            h->used_bound += extra;
+            h->kmers_bound = inst;
+            return KQ_OK;
+        }
+    }
+    int rc = read_state(h);
+    if (rc) return rc;
+    const uint64_t used = h->st_host->slots_used;
+    h->used_bound = used + extra;
+    uint64_t need_slots = (uint64_t)((double)(used + extra) / 0.85) + REGION_SLOTS;
+    if (need_slots > h->n_slots()) {
+        uint64_t want = h->n_slots();
+        while (want < need_slots) want *= 2;
+        uint64_t new_regions = want >> REGION_SHIFT;
+        Slot* fresh = nullptr;
+        rc = alloc_main(h, new_regions, &fresh);
+        if (rc) return rc == KQ_ERR_NOMEM ? fail(KQ_ERR_TABLE_FULL, "cannot grow k-mer table to %llu slots: out of device memory",
+                                                 (unsigned long long)want) : rc;
+        Slot* old = h->slots; uint64_t n_old = h->n_slots();
+        h->slots = fresh; h->n_regions = new_regions;
+        hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old, n_old);
+        HIPC(hipStreamSynchronize(h->stream));
+        HIPC(hipFree(old));
+    }
+    // side table: #keys with cov >= 255 <= instances / 255; keep load <= 0.5, but never reserve
+    // more than 2^24 slots (1.2 GB) up front -- beyond that growth follows the observed fill.
+    h->kmers_bound += extra_instances;
+    uint64_t bound = h->kmers_bound / 255 + 1;
+    uint64_t need_hc = 2 * std::min<uint64_t>(bound, 1ull << 23);
+    need_hc = std::max<uint64_t>(need_hc, 4 * h->st_host->hc_used);
+    if (need_hc > h->hc_cap) {
+        uint64_t want = h->hc_cap;
+        while (want < need_hc) want *= 2;
+        HcSlot* fresh = nullptr;
+        rc = alloc_hc(h, want, &fresh);
+        if (rc) return rc;
+        HcSlot* old = h->hc; uint64_t n_old = h->hc_cap;
+        h->hc = fresh; h->hc_cap = want;
+        HIPC(hipMemsetAsync(&h->st->hc_used, 0, sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(k_rehash_hc, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old, n_old);
+        HIPC(hipStreamSynchronize(h->stream));
+        HIPC(hipFree(old));
+    }
+    return KQ_OK;
+}
+
+// aligned view of a device byte string: 16-byte aligned base + lead
+static inline void aligned_view(const char* d, const uint8_t** ab, uint64_t* lead) {
+    uintptr_t p = (uintptr_t)d;
+    *lead = p & 15;
+    *ab = (const uint8_t*)(p - *lead);
+}
+
+static int stage_in(kq_handle* h, const void* host, size_t bytes, void** dev) {
+    int rc = ensure_buf(&h->stage, &h->stage_bytes, bytes + 64);
+    if (rc) return rc;
+    if (bytes) HIPC(hipMemcpyAsync(h->stage, host, bytes, hipMemcpyHostToDevice, h->stream));
+    *dev = h->stage;
+    return KQ_OK;
+}
+
+extern "C" {
+
+const char* kq_last_error(void) { return g_err.c_str(); }
+int kq_abi_version(void) { return KQ_ABI_VERSION; }
+
+int kq_device_available(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return 0;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capacity_hint) {
+    if (!out) return fail(KQ_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (k < 2 || k > 32) return fail(KQ_ERR_INVALID, "k must be in 2..32 (got %d)", k);       // src/input.cpp:142
+    if (map_count < 1 || map_count > 65535) return fail(KQ_ERR_INVALID, "map_count must be in 1..65535 (got %d)", map_count);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(KQ_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(KQ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    HIPC(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPC(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(KQ_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    kq_handle* h = new (std::nothrow) kq_handle();
+    if (!h) return fail(KQ_ERR_NOMEM, "host allocation failed");
+    h->device = device; h->k = k; h->map_count = map_count; h->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(KQ_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    h->stream = h->own_stream;
+    int rc = KQ_OK;
+    do {
+        if (hipMalloc((void**)&h->st, sizeof(DevState)) != hipSuccess || hipHostMalloc((void**)&h->st_host, sizeof(DevState)) != hipSuccess) {
+            rc = fail(KQ_ERR_NOMEM, "state allocation failed"); break;
+        }
+        hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream);
+        uint64_t slots = (uint64_t)((double)(capacity_hint ? capacity_hint : (1u << 20)) / 0.6);
+        uint64_t regions = (slots + REGION_SLOTS - 1) >> REGION_SHIFT;
+        if (regions < 16) regions = 16;
+        rc = alloc_main(h, regions, &h->slots); if (rc) break;
+        h->n_regions = regions;
+        uint64_t hc = 1u << 16;
+        rc = alloc_hc(h, hc, &h->hc); if (rc) break;
+        h->hc_cap = hc;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(KQ_ERR_HIP, "table initialisation failed"); break; }
+    } while (0);
+    if (rc) { kq_destroy(h); return rc; }
+    *out = h;
+    return KQ_OK;
+}
+
+void kq_destroy(kq_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->slots) hipFree(h->slots);
+    if (h->hc) hipFree(h->hc);
+    if (h->st) hipFree(h->st);
+    if (h->st_host) hipHostFree(h->st_host);
+    if (h->scratch) hipFree(h->scratch);
+    if (h->stage) hipFree(h->stage);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int kq_clear(kq_handle* h) {
+    if (!h) return fail(KQ_ERR_INVALID, "null handle");
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipMemsetAsync(h->slots, 0, (size_t)h->n_slots() * sizeof(Slot), h->stream));
+    hipLaunchKernelGGL(k_fill_keys, dim3(grid_for(h, h->n_slots(), 256)), dim3(256), 0, h->stream, (uint64_t*)h->slots, (uint64_t)3, h->n_slots());
+    HIPC(hipMemsetAsync(h->hc, 0, (size_t)h->hc_cap * sizeof(HcSlot), h->stream));
+    hipLaunchKernelGGL(k_fill_keys, dim3(grid_for(h, h->hc_cap, 256)), dim3(256), 0, h->stream, (uint64_t*)h->hc, (uint64_t)9, h->hc_cap);
+    HIPC(hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream));
+    h->kmers_bound = 0;
+    h->used_bound = 0;
+    return KQ_OK;
+}
+
+int kq_set_stream(kq_handle* h, void* s) {
+    if (!h) return fail(KQ_ERR_INVALID, "null handle");
+    HIPC(hipStreamSynchronize(h->stream));
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return KQ_OK;
+}
+void* kq_get_stream(kq_handle* h) { return h ? (void*)h->stream : nullptr; }
+int kq_sync(kq_handle* h) {
+    if (!h) return fail(KQ_ERR_INVALID, "null handle");
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipStreamSynchronize(h->stream));
+    return check_errors(h);
+}
+int kq_get_info(kq_handle* h, kq_info* out) {
+    if (!h || !out) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    int rc = read_state(h);
+    if (rc) return rc;
+    out->kmers_counted = h->st_host->kmers_added;
+    out->slots_used = h->st_host->slots_used;
+    out->slots_total = h->n_slots();
+    out->hc_used = h->st_host->hc_used;
+    out->hc_total = h->hc_cap;
+    out->table_bytes = h->n_slots() * sizeof(Slot) + h->hc_cap * sizeof(HcSlot);
+    return KQ_OK;
+}
+
+// ---- count ---------------------------------------------------------------------------------
+int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
+    if (!h || (!d_bases && len)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    if (len < (uint64_t)h->k) return KQ_OK;                                  // src/graph-builder.cpp:60
+    const uint64_t kmers = len - h->k + 1;
+    int rc = reserve(h, kmers, kmers);
+    if (rc) return rc;
+    const uint8_t* ab; uint64_t lead;
+    aligned_view(d_bases, &ab, &lead);
+    hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, len), 1)), dim3(TILE_THREADS), 0, h->stream,
+                       h->view(), ab, lead, len, h->k);
+    HIPC(hipGetLastError());
+    return KQ_OK;
+}
+int kq_count_batch(kq_handle* h, const char* bases, uint64_t len) {
+    if (!h || (!bases && len)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    void* d = nullptr;
+    int rc = stage_in(h, bases, len, &d);
+    if (rc) return rc;
+    rc = kq_count_batch_dev(h, (const char*)d, len);
+    if (rc) return rc;
+    return kq_sync(h);
+}
+
+static int emit_ordered(kq_handle* h, const char* d_bases, uint64_t len, uint64_t* d_keys, uint8_t* d_edges, uint64_t cap,
+                        uint64_t* n_out) {
+    const uint8_t* ab; uint64_t lead;
+    aligned_view(d_bases, &ab, &lead);
+    const uint64_t nt = n_tiles_of(lead, len);
+    int rc = ensure_buf(&h->scratch, &h->scratch_bytes, (nt + 2) * sizeof(unsigned long long));
+    if (rc) return rc;
+    unsigned long long* tile_counts = (unsigned long long*)h->scratch;
+    unsigned long long* total = tile_counts + nt;
+    int grid = grid_for(h, nt, 1);
+    hipLaunchKernelGGL(k_emit_count, dim3(grid), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, tile_counts);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, tile_counts, nt, total);
+    unsigned long long n = 0;
+    HIPC(hipMemcpyAsync(&n, total, sizeof n, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    *n_out = n;
+    if (!d_keys || !d_edges) return KQ_OK;
+    if (n > cap) return fail(KQ_ERR_CAPACITY, "record buffer too small: need %llu, have %llu", n, (unsigned long long)cap);
+    hipLaunchKernelGGL(k_emit_write, dim3(grid), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, tile_counts, d_keys, d_edges, cap);
+    HIPC(hipGetLastError());
+    return KQ_OK;
+}
+
+int kq_emit_records(kq_handle* h, const char* bases, uint64_t len, uint64_t* keys, uint8_t* edges, uint64_t cap, uint64_t* n_out) {
+    if (!h || !n_out || (!bases && len)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    *n_out = 0;
+    if (len < (uint64_t)h->k) return KQ_OK;
+    void* d = nullptr;
+    int rc = stage_in(h, bases, len, &d);
+    if (rc) return rc;
+    if (!keys || !edges) return emit_ordered(h, (const char*)d, len, nullptr, nullptr, 0, n_out);
+    rc = emit_ordered(h, (const char*)d, len, nullptr, nullptr, 0, n_out);
+    if (rc) return rc;
+    if (*n_out > cap) return fail(KQ_ERR_CAPACITY, "record buffer too small: need %llu, have %llu", (unsigned long long)*n_out, (unsigned long long)cap);
+    uint64_t n = *n_out;
+    uint64_t* dk = nullptr; uint8_t* de = nullptr;
+    if (n) {
+        HIPC(hipMalloc((void**)&dk, n * sizeof(uint64_t)));
+        if (hipMalloc((void**)&de, n) != hipSuccess) { hipFree(dk); return fail(KQ_ERR_NOMEM, "record buffer allocation failed"); }
+        rc = emit_ordered(h, (const char*)d, len, dk, de, n, n_out);
+        if (!rc) {
+            hipError_t e1 = hipMemcpyAsync(keys, dk, n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream);
+            hipError_t e2 = hipMemcpyAsync(edges, de, n, hipMemcpyDeviceToHost, h->stream);
+            hipError_t e3 = hipStreamSynchronize(h->stream);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(KQ_ERR_HIP, "copying records back failed");
+        }
+        hipFree(dk); hipFree(de);
+    }
+    return rc;
+}
+
+int kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts, uint64_t* d_keys, uint8_t* d_edges,
+                            uint64_t cap, uint64_t* part_counts) {
+    if (!h || !part_counts || n_parts < 1 || n_parts > h->map_count || (!d_bases && len)) return fail(KQ_ERR_INVALID, "bad argument");
+    HIPC(hipSetDevice(h->device));
+    for (int i = 0; i < n_parts; ++i) part_counts[i] = 0;
+    if (len < (uint64_t)h->k) return KQ_OK;
+    const uint8_t* ab; uint64_t lead;
+    aligned_view(d_bases, &ab, &lead);
+    int rc = ensure_buf(&h->scratch, &h->scratch_bytes, 2 * (size_t)n_parts * sizeof(unsigned long long));
+    if (rc) return rc;
+    unsigned long long* counts = (unsigned long long*)h->scratch;
+    unsigned long long* cursor = counts + n_parts;
+    HIPC(hipMemsetAsync(counts, 0, (size_t)n_parts * sizeof(unsigned long long), h->stream));
+    int grid = grid_for(h, n_tiles_of(lead, len), 1);
+    hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(TILE_THREADS), (size_t)n_parts * sizeof(unsigned long long), h->stream,
+                       ab, lead, len, h->k, (uint32_t)h->map_count, (uint32_t)n_parts, counts);
+    std::vector<unsigned long long> hc(n_parts), off(n_parts);
+    HIPC(hipMemcpyAsync(hc.data(), counts, (size_t)n_parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    unsigned long long run = 0;
+    for (int i = 0; i < n_parts; ++i) { off[i] = run; run += hc[i]; part_counts[i] = hc[i]; }
+    if (run > cap) return fail(KQ_ERR_CAPACITY, "record buffer too small: need %llu, have %llu", run, (unsigned long long)cap);
+    HIPC(hipMemcpyAsync(cursor, off.data(), (size_t)n_parts * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, (uint32_t)h->map_count,
+                       (uint32_t)n_parts, cursor, d_keys, d_edges, cap);
+    HIPC(hipStreamSynchronize(h->stream));   // off[] is a stack vector: keep it alive until the copy is done
+    return KQ_OK;
+}
+
+int kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d_edges, uint64_t n) {
+    if (!h || ((!d_keys || !d_edges) && n)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    if (!n) return KQ_OK;
+    int rc = reserve(h, n, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_insert_records, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, h->view(), d_keys, d_edges, n);
+    HIPC(hipGetLastError());
+    return KQ_OK;
+}
+int kq_insert_records(kq_handle* h, const uint64_t* keys, const uint8_t* edges, uint64_t n) {
+    if (!h || ((!keys || !edges) && n)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    if (!n) return KQ_OK;
+    int rc = ensure_buf(&h->stage, &h->stage_bytes, n * 9 + 64);
+    if (rc) return rc;
+    uint64_t* dk = (uint64_t*)h->stage;
+    uint8_t* de = (uint8_t*)h->stage + n * 8;
+    HIPC(hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPC(hipMemcpyAsync(de, edges, n, hipMemcpyHostToDevice, h->stream));
+    rc = kq_insert_records_dev(h, dk, de, n);
+    if (rc) return rc;
+    return kq_sync(h);
+}
+
+// ---- summary ---------------------------------------------------------------------------------
+struct SummaryHost { SummaryOut so; std::vector<unsigned long long> small; std::vector<uint32_t> big; };
+static int run_summary(kq_handle* h, SummaryHost* r) {
+    const uint64_t big_cap = h->hc_cap;     // cov >= 4096 implies a high-copy k-mer
+    size_t need = sizeof(SummaryOut) + HIST_SMALL * sizeof(unsigned long long) + big_cap * sizeof(uint32_t);
+    int rc = ensure_buf(&h->scratch, &h->scratch_bytes, need);
+    if (rc) return rc;
+    SummaryOut* d_so = (SummaryOut*)h->scratch;
+    unsigned long long* d_small = (unsigned long long*)(d_so + 1);
+    uint32_t* d_big = (uint32_t*)(d_small + HIST_SMALL);
+    HIPC(hipMemsetAsync(h->scratch, 0, sizeof(SummaryOut) + HIST_SMALL * sizeof(unsigned long long), h->stream));
+    SummaryOut init; memset(&init, 0, sizeof init); init.big_cap = big_cap;
+    HIPC(hipMemcpyAsync(d_so, &init, sizeof init, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_summary, dim3(grid_for(h, h->n_slots(), 1024)), dim3(256), 0, h->stream, h->view(), d_so, d_small, d_big);
+    r->small.resize(HIST_SMALL);
+    HIPC(hipMemcpyAsync(&r->so, d_so, sizeof(SummaryOut), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipMemcpyAsync(r->small.data(), d_small, HIST_SMALL * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    if (r->so.n_big > big_cap) return fail(KQ_ERR_HIP, "summary: high-coverage list overflow");
+    r->big.resize(r->so.n_big);
+    if (r->so.n_big) {
+        HIPC(hipMemcpyAsync(r->big.data(), d_big, r->so.n_big * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPC(hipStreamSynchronize(h->stream));
+    }
+    return KQ_OK;
+}
+int kq_summary(kq_handle* h, kq_stats* out) {
+    if (!h || !out) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    int rc = check_errors(h);
+    if (rc) return rc;
+    SummaryHost r;
+    rc = run_summary(h, &r);
+    if (rc) return rc;
+    out->total = r.so.total; out->unique = r.so.uniq; out->distinct = r.so.distinct; out->edges = r.so.edges;
+    const uint64_t space = h->k < 32 ? (1ull << (2 * h->k)) : 0ull;          // src/graph-builder.cpp:286
+    out->missing = space - out->distinct;
+    return KQ_OK;
+}
+int kq_histogram(kq_handle* h, uint64_t* cov, uint64_t* cnt, uint64_t cap, uint64_t* n_out) {
+    if (!h || !n_out) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    int rc = check_errors(h);
+    if (rc) return rc;
+    SummaryHost r;
+    rc = run_summary(h, &r);
+    if (rc) return rc;
+    std::vector<std::pair<uint64_t, uint64_t>> hist;
+    for (uint32_t c = 0; c < HIST_SMALL; ++c) if (r.small[c]) hist.emplace_back(c, r.small[c]);
+    std::sort(r.big.begin(), r.big.end());
+    for (size_t i = 0; i < r.big.size();) {
+        size_t j = i; while (j < r.big.size() && r.big[j] == r.big[i]) ++j;
+        hist.emplace_back(r.big[i], j - i);
+        i = j;
+    }
+    *n_out = hist.size();
+    if (!cov || !cnt) return KQ_OK;
+    if (hist.size() > cap) return fail(KQ_ERR_CAPACITY, "histogram buffer too small: need %zu", hist.size());
+    for (size_t i = 0; i < hist.size(); ++i) { cov[i] = hist[i].first; cnt[i] = hist[i].second; }
+    return KQ_OK;
+}
+
+// ---- lookup ----------------------------------------------------------------------------------
+int kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uint32_t cov_cutoff, uint16_t map_lo, uint16_t map_hi,
+                           kq_dbgbase* d_per_base, uint64_t* d_counters) {
+    if (!h || !d_counters || (!d_bases && len)) return fail(KQ_ERR_INVALID, "null argument");
+    if (map_lo > map_hi || map_hi > h->map_count) return fail(KQ_ERR_INVALID, "map range [%u,%u) outside [0,%d]", map_lo, map_hi, h->map_count);
+    HIPC(hipSetDevice(h->device));
+    if (len < (uint64_t)h->k) return KQ_OK;                                  // src/kreeq.cpp:123
+    const uint8_t* ab; uint64_t lead;
+    aligned_view(d_bases, &ab, &lead);
+    hipLaunchKernelGGL(k_lookup, dim3(grid_for(h, n_tiles_of(lead, len), 1)), dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len,
+                       h->k, (uint32_t)h->map_count, (uint32_t)map_lo, (uint32_t)map_hi, cov_cutoff, d_per_base,
+                       (unsigned long long*)d_counters);
+    HIPC(hipGetLastError());
+    return KQ_OK;
+}
+int kq_lookup_sequence(kq_handle* h, const char* bases, uint64_t len, uint32_t cov_cutoff, uint16_t map_lo, uint16_t map_hi,
+                       kq_dbgbase* per_base, uint64_t counters[3]) {
+    if (!h || !counters || (!bases && len)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    int rc = check_errors(h);
+    if (rc) return rc;
+    void* d = nullptr;
+    rc = stage_in(h, bases, len, &d);
+    if (rc) return rc;
+    unsigned long long* d_ctr = nullptr;
+    kq_dbgbase* d_pb = nullptr;
+    HIPC(hipMalloc((void**)&d_ctr, 3 * sizeof(unsigned long long)));
+    hipMemsetAsync(d_ctr, 0, 3 * sizeof(unsigned long long), h->stream);
+    if (per_base && len) {
+        if (hipMalloc((void**)&d_pb, len * sizeof(kq_dbgbase)) != hipSuccess) { hipFree(d_ctr); return fail(KQ_ERR_NOMEM, "per-base buffer allocation failed"); }
+        hipMemcpyAsync(d_pb, per_base, len * sizeof(kq_dbgbase), hipMemcpyHostToDevice, h->stream);
+    }
+    rc = kq_lookup_sequence_dev(h, (const char*)d, len, cov_cutoff, map_lo, map_hi, d_pb, (uint64_t*)d_ctr);
+    unsigned long long c[3] = {0, 0, 0};
+    if (!rc) {
+        hipError_t e1 = hipMemcpyAsync(c, d_ctr, sizeof c, hipMemcpyDeviceToHost, h->stream);
+        hipError_t e2 = d_pb ? hipMemcpyAsync(per_base, d_pb, len * sizeof(kq_dbgbase), hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+        hipError_t e3 = hipStreamSynchronize(h->stream);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(KQ_ERR_HIP, "lookup failed: %s", hipGetErrorString(e3));
+    }
+    hipFree(d_ctr);
+    if (d_pb) hipFree(d_pb);
+    if (!rc) for (int i = 0; i < 3; ++i) counters[i] += c[i];
+    return rc;
+}
+
+// ---- union / import / export ---------------------------------------------------------------------
+int kq_merge(kq_handle* dst, kq_handle* src) {
+    if (!dst || !src) return fail(KQ_ERR_INVALID, "null handle");
+    if (dst == src) return fail(KQ_ERR_INVALID, "cannot merge a handle into itself");
+    if (dst->k != src->k || dst->map_count != src->map_count || dst->device != src->device)
+        return fail(KQ_ERR_MISMATCH, "handles differ in k / map_count / device");    // src/input.cpp:136-139
+    HIPC(hipSetDevice(dst->device));
+    int rc = kq_sync(src);
+    if (rc) return rc;
+    rc = read_state(src);
+    if (rc) return rc;
+    rc = reserve(dst, src->st_host->slots_used, src->st_host->kmers_added);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_merge, dim3(grid_for(dst, src->n_slots(), 256)), dim3(256), 0, dst->stream, dst->view(), src->view());
+    HIPC(hipGetLastError());
+    return kq_sync(dst);
+}
+
+int kq_import(kq_handle* h, const kq_entry* entries, uint64_t n) {
+    if (!h || (!entries && n)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    if (!n) return KQ_OK;
+    uint64_t inst = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const kq_entry& e = entries[i];
+        inst += e.cov;
+        bool ok = e.cov > 0 && e.key != EMPTY_KEY;
+        for (int w = 0; w < 4; ++w) ok = ok && e.fw[w] <= e.cov && e.bw[w] <= e.cov;   // an edge is seen at most once per instance
+        if (!ok) return fail(KQ_ERR_INVALID, "entry %llu is not a valid k-mer record (cov 0, or an edge counter above cov)",
+                             (unsigned long long)i);
+    }
+    int rc = reserve(h, n, inst);
+    if (rc) return rc;
+    void* d = nullptr;
+    rc = stage_in(h, entries, n * sizeof(kq_entry), &d);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_import, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, h->view(), (const kq_entry*)d, n);
+    HIPC(hipGetLastError());
+    return kq_sync(h);
+}
+
+int kq_export(kq_handle* h, uint16_t map_lo, uint16_t map_hi, kq_entry* out, uint64_t cap, uint64_t* n_out) {
+    if (!h || !n_out) return fail(KQ_ERR_INVALID, "null argument");
+    if (map_lo > map_hi || map_hi > h->map_count) return fail(KQ_ERR_INVALID, "map range [%u,%u) outside [0,%d]", map_lo, map_hi, h->map_count);
+    HIPC(hipSetDevice(h->device));
+    int rc = check_errors(h);
+    if (rc) return rc;
+    unsigned long long* d_n = nullptr;
+    kq_entry* d_out = nullptr;
+    HIPC(hipMalloc((void**)&d_n, sizeof(unsigned long long)));
+    hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream);
+    if (out && cap) {
+        if (hipMalloc((void**)&d_out, cap * sizeof(kq_entry)) != hipSuccess) { hipFree(d_n); return fail(KQ_ERR_NOMEM, "export buffer allocation failed"); }
+    }
+    hipLaunchKernelGGL(k_export, dim3(grid_for(h, h->n_slots(), 1024)), dim3(256), 0, h->stream, h->view(), (uint32_t)h->map_count,
+                       (uint32_t)map_lo, (uint32_t)map_hi, d_out, d_out ? cap : 0, d_n);
+    unsigned long long n = 0;
+    hipError_t e = hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = fail(KQ_ERR_HIP, "export failed: %s", hipGetErrorString(e));
+    *n_out = n;
+    if (!rc && out) {
+        if (n > cap) rc = fail(KQ_ERR_CAPACITY, "export buffer too small: need %llu, have %llu", n, (unsigned long long)cap);
+        else if (n) {
+            e = hipMemcpy(out, d_out, n * sizeof(kq_entry), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail(KQ_ERR_HIP, "export copy failed: %s", hipGetErrorString(e));
+            else std::sort(out, out + n, [](const kq_entry& a, const kq_entry& b) { return a.key < b.key; });
+        }
+    }
+    hipFree(d_n);
+    if (d_out) hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

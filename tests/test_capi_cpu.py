@@ -1,0 +1,56 @@
+"""CPU-side checks of the product boundary: the C-ABI library builds for gfx950, loads, exports
+every symbol include/kreeq_amd.h declares, and fails loudly (no CPU fallback) without a GPU."""
+import os
+import re
+
+import pytest
+
+from kreeq_amd import build, capi
+from tests.helpers import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_lib()
+    return capi.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "kreeq_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(kq_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(capi.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def test_abi_version(lib):
+    assert lib.kq_abi_version() == 1
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert not capi.device_available()
+    with pytest.raises(capi.KqError) as e:
+        capi.KreeqDB(21, 128)
+    assert e.value.code == -2 and "no CPU path" in str(e.value)
+
+
+def test_bad_arguments_rejected_before_device(lib):
+    for k in (0, 1, 33):
+        with pytest.raises(capi.KqError) as e:
+            capi.KreeqDB(k, 128)
+        assert e.value.code == -1
+
+
+def test_product_does_not_touch_oracle():
+    """the oracle is test infrastructure: nothing under kreeq_amd/ or include/ may reference it"""
+    for base in ("kreeq_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".c")):
+                    txt = open(os.path.join(dp, f), errors="replace").read()
+                    assert "oracle" not in txt.lower(), os.path.join(dp, f)

@@ -1,0 +1,298 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and against the
+reference's committed goldens.  Bit-exact (integer counts, printed QV text)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kq():
+    import kreeq_amd
+
+    if not kreeq_amd.device_available():
+        pytest.fail("no gfx950 device: the product path has no CPU fallback")
+    return kreeq_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+VALIDATE_TESTS = [i for i in range(0, 35) if not 15 <= i <= 19]
+DB_READS = {"test1": "random1.fastq", "test2": "random2.fastq", "random5": "random5.fastq", "random6": "random6.fastq",
+            "random7": "random7.fastq", "random8": "random8.fastq", "random9": "random9.fastq", "random10": "random10.fastq",
+            "random11": "random11.fastq", "random12": "random12.fastq"}
+
+
+# ---------------------------------------------------------------------------------- K1 emit
+@pytest.mark.parametrize("name", ["random1.fastq", "random2.fastq", "random3.N.fastq", "repeat1.fastq", "to_correct.fastq"])
+def test_emit_records_fixtures(kq, O, name):
+    batch = H.reads_batch([H.golden_input(name)])
+    db = kq.KreeqDB(21, 128)
+    keys, edges = db.emit_records(batch)
+    ok, oe = O.emit_records(21, batch)
+    assert np.array_equal(keys, ok) and np.array_equal(edges, oe)
+
+
+@pytest.mark.parametrize("k", [2, 5, 16, 21, 31, 32])
+def test_emit_records_random(kq, O, k):
+    batch, _ = H.synth_reads(700, 97, 5000, seed=100 + k, err=0.02, n_rate=0.01)
+    db = kq.KreeqDB(k, 128)
+    for cut in (len(batch), 4032, 4031, 4033, 8064 + 5, 17, k, k - 1, 0):
+        b = batch[:cut]
+        keys, edges = db.emit_records(b)
+        ok, oe = O.emit_records(k, b)
+        assert np.array_equal(keys, ok), (k, cut)
+        assert np.array_equal(edges, oe), (k, cut)
+
+
+def test_emit_odd_bytes(kq, O):
+    """every byte value: only ACGTacgt are bases"""
+    rng = np.random.default_rng(5)
+    raw = rng.integers(0, 256, 20000, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+    mask = rng.random(20000) < 0.93
+    raw = np.where(mask, acgt[rng.integers(0, 8, 20000)], raw).astype(np.uint8)
+    b = raw.tobytes()
+    db = kq.KreeqDB(11, 128)
+    keys, edges = db.emit_records(b)
+    ok, oe = O.emit_records(11, b)
+    assert len(ok) > 1000
+    assert np.array_equal(keys, ok) and np.array_equal(edges, oe)
+
+
+# ---------------------------------------------------------------------------------- count
+@pytest.mark.parametrize("name", sorted(DB_READS))
+def test_count_reproduces_fixture_db(kq, name):
+    db = kq.KreeqDB(21, 128)
+    db.count_batch(H.reads_batch([H.golden_input(DB_READS[name])]))
+    assert H.entries_equal(db.export(), H.load_db_table(name))
+
+
+@pytest.mark.parametrize("idx", VALIDATE_TESTS)
+def test_validate_stdout_goldens(kq, O, idx):
+    argv, expected = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", f"test.{idx}.tst"))
+    asm, reads = H.parse_validate_cmd(argv)
+    db = kq.KreeqDB(21, 128)
+    for r in reads:
+        db.count_batch(H.reads_batch([H.golden_input(r)]))
+    out = H.stats_block(db.summary())
+    ctr = np.zeros(3, dtype=np.uint64)
+    for _, seq in H.read_fastx(H.golden_input(asm)):
+        c, _ = db.lookup_sequence(seq)
+        ctr += c
+    # the two doubles are computed on the host from the three integers (errorRate, src/kreeq.cpp:36-40)
+    out += H.qv_block(int(ctr[0]), int(ctr[1]), int(ctr[2]), 21, O.error_rate, O.qv)
+    assert out == expected
+
+
+def test_union_golden(kq):
+    argv, expected = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.35.tst"))
+    a, b = kq.KreeqDB(21, 128), kq.KreeqDB(21, 128)
+    a.import_entries(H.load_db_table("test1"))
+    b.import_entries(H.load_db_table("test2"))
+    assert H.entries_equal(a.export(), H.load_db_table("test1"))
+    a.merge(b)
+    assert H.stats_block(a.summary()) == expected
+    c = kq.KreeqDB(21, 128)
+    c.count_batch(H.reads_batch([H.golden_input("random1.fastq")]))
+    c.count_batch(H.reads_batch([H.golden_input("random2.fastq")]))
+    assert H.entries_equal(a.export(), c.export())
+    # importing two databases into one handle is the same union
+    d = kq.KreeqDB(21, 128)
+    d.import_entries(H.load_db_table("test1"))
+    d.import_entries(H.load_db_table("test2"))
+    assert H.entries_equal(a.export(), d.export())
+
+
+@pytest.mark.parametrize("asm,reads,bkwig", [("repeat1.fasta", "repeat1.fastq", "decompressor2.bkwig"),
+                                            ("decompressor1.fasta", "random1.fastq", "decompressor1.bkwig")])
+def test_bkwig_per_base(kq, asm, reads, bkwig):
+    from tests.test_oracle_golden import per_base_triplets, read_bkwig
+
+    k, vals = read_bkwig(H.golden_input(bkwig))
+    db = kq.KreeqDB(k, 128)
+    db.count_batch(H.reads_batch([H.golden_input(reads)]))
+    seqs = dict(H.read_fastx(H.golden_input(asm)))
+    for hdr, pos, a in vals:
+        _, pb = db.lookup_sequence(seqs[hdr], per_base=True)
+        assert np.array_equal(per_base_triplets(pb[pos:pos + len(a)]), a), (hdr, pos)
+
+
+@pytest.mark.parametrize("k,seed", [(21, 1), (31, 2), (32, 3), (9, 4)])
+def test_count_random_vs_oracle(kq, O, k, seed):
+    batch, genome = H.synth_reads(20000, 150, 60000, seed=seed, err=0.01, n_rate=0.003)
+    gpu, cpu = kq.KreeqDB(k, 128), O.OracleDB(k, 128)
+    gpu.count_batch(batch)
+    cpu.count_batch(batch, threads=8)
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(gpu.export(), cpu.export())
+    # per-map export agrees and is a partition of the whole
+    n = 0
+    for lo, hi in ((0, 1), (1, 64), (64, 128)):
+        e = gpu.export(lo, hi)
+        assert np.all((e["key"] % 128 >= lo) & (e["key"] % 128 < hi))
+        n += len(e)
+    assert n == gpu.summary()["distinct"]
+    # lookup: whole genome, with per-base output, cutoff and map ranges
+    for cutoff in (0, 3):
+        cg, pg = gpu.lookup_sequence(genome, cov_cutoff=cutoff, per_base=True)
+        cc, pc = cpu.validate_sequence(genome, cov_cutoff=cutoff, per_base=True, threads=8)
+        assert np.array_equal(cg, cc)
+        for f in ("fw", "bw", "cov", "isFw"):
+            assert np.array_equal(pg[f], pc[f]), f
+    ctr = np.zeros(3, dtype=np.uint64)
+    pb = np.zeros(len(genome), dtype=kq.DBGBASE_DTYPE)
+    for lo, hi in ((0, 40), (40, 41), (41, 128)):          # map-range passes accumulate (src/kreeq.cpp:59-76)
+        c, pb = gpu.lookup_sequence(genome, map_lo=lo, map_hi=hi, per_base_buf=pb)
+        ctr += c
+    cc, pc = cpu.validate_sequence(genome, per_base=True)
+    assert np.array_equal(ctr, cc)
+    for f in ("fw", "bw", "cov", "isFw"):
+        assert np.array_equal(pb[f], pc[f]), f
+
+
+def test_overflow_to_high_copy(kq, O):
+    """u8 -> u32 tier (src/graph-builder.cpp:166-205): order-independent exact sums, hc iff cov >= 255"""
+    rng = np.random.default_rng(7)
+    keys = np.concatenate([np.full(3000, 5 * 128 + 3, dtype=np.uint64), np.full(254, 9 * 128 + 3, dtype=np.uint64),
+                           np.full(255, 11 * 128 + 3, dtype=np.uint64), np.full(70000, 12345678901, dtype=np.uint64),
+                           rng.integers(0, 50, 20000).astype(np.uint64)])
+    edges = rng.integers(0, 256, len(keys)).astype(np.uint8)
+    p = rng.permutation(len(keys))
+    gpu, cpu = kq.KreeqDB(21, 128), O.OracleDB(21, 128)
+    gpu.insert_records(keys[p], edges[p])
+    cpu.insert_records(keys, edges)
+    assert H.entries_equal(gpu.export(), cpu.export())
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    # homopolymer reads: one k-mer hammered from every lane
+    batch = b"\n".join([b"A" * 500, b"T" * 777, b"ACGT" * 100, b"a" * 30])
+    g2, c2 = kq.KreeqDB(21, 128), O.OracleDB(21, 128)
+    for _ in range(3):
+        g2.count_batch(batch)
+        c2.count_batch(batch)
+    assert H.entries_equal(g2.export(), c2.export())
+    cg, pg = g2.lookup_sequence(b"A" * 50 + b"N" + b"T" * 40, per_base=True)
+    cc, pc = c2.validate_sequence(b"A" * 50 + b"N" + b"T" * 40, per_base=True)
+    assert np.array_equal(cg, cc)
+    for f in ("fw", "bw", "cov", "isFw"):
+        assert np.array_equal(pg[f], pc[f])
+
+
+def test_saturation_at_largest(kq, O):
+    """counters saturate at 2^32-1 (include/kreeq.h:68; src/graph-builder.cpp:198-204, :316-329)"""
+    big = np.zeros(3, dtype=kq.ENTRY_DTYPE)
+    big["key"] = [7, 8, 9]
+    big["cov"] = [4294967295, 4294967290, 3000000000]
+    big["fw"][:, 1] = [4294967295, 4294967290, 2999999999]
+    big["bw"][:, 2] = [17, 4294967289, 5]
+    big["hc"] = 1
+    gpu, cpu = kq.KreeqDB(21, 128), O.OracleDB(21, 128)
+    gpu.import_entries(big)
+    cpu.import_entries(big)
+    assert H.entries_equal(gpu.export(), cpu.export())
+    keys = np.repeat(np.array([7, 8, 9], dtype=np.uint64), 20)
+    edges = np.full(60, 0b01000010, dtype=np.uint8)      # fw[1] and bw[2]
+    gpu.insert_records(keys, edges)
+    cpu.insert_records(keys, edges)
+    assert H.entries_equal(gpu.export(), cpu.export())
+    g2, c2 = kq.KreeqDB(21, 128), O.OracleDB(21, 128)
+    g2.import_entries(big)
+    c2.import_entries(big)
+    gpu.merge(g2)
+    cpu.merge(c2)
+    out = gpu.export()
+    assert H.entries_equal(out, cpu.export())
+    assert out["cov"].max() == 4294967295
+    assert gpu.summary() == cpu.summary()
+
+
+def test_table_growth(kq, O):
+    """tiny capacity hint: the table must grow by rehashing without losing a count"""
+    batch, _ = H.synth_reads(30000, 120, 3_000_000, seed=21, err=0.0)
+    gpu, cpu = kq.KreeqDB(25, 128, capacity_hint=1000), O.OracleDB(25, 128)
+    third = len(batch) // 3
+    cuts = [batch.rfind(b"\n", 0, third), batch.rfind(b"\n", 0, 2 * third)]
+    parts = [batch[:cuts[0]], batch[cuts[0] + 1:cuts[1]], batch[cuts[1] + 1:]]
+    before = gpu.info()["slots_total"]
+    for p in parts:
+        gpu.count_batch(p)
+        cpu.count_batch(p, threads=8)
+    assert gpu.info()["slots_total"] > before
+    assert gpu.info()["slots_used"] == cpu.summary()["distinct"]
+    assert H.entries_equal(gpu.export(), cpu.export())
+
+
+def test_device_pointer_entry_points(kq, O):
+    """*_dev variants on torch-owned HBM, including a misaligned base pointer"""
+    import torch
+
+    batch, genome = H.synth_reads(5000, 150, 40000, seed=33, err=0.01, n_rate=0.002)
+    cpu = O.OracleDB(21, 128)
+    cpu.count_batch(batch)
+    for shift in (0, 1, 7, 15):
+        t = torch.zeros(len(batch) + 64, dtype=torch.uint8, device="cuda")
+        t[shift:shift + len(batch)] = torch.frombuffer(bytearray(batch), dtype=torch.uint8).cuda()
+        gpu = kq.KreeqDB(21, 128)
+        gpu.count_batch_dev(t.data_ptr() + shift, len(batch))
+        gpu.sync()
+        assert H.entries_equal(gpu.export(), cpu.export()), shift
+        g = torch.frombuffer(bytearray(genome), dtype=torch.uint8).cuda()
+        ctr = torch.zeros(3, dtype=torch.int64, device="cuda")
+        gpu.lookup_sequence_dev(g.data_ptr(), len(genome), ctr.data_ptr())
+        gpu.sync()
+        cc, _ = cpu.validate_sequence(genome)
+        assert ctr.cpu().numpy().astype(np.uint64).tolist() == cc.tolist()
+
+
+def test_emit_partitioned_then_insert(kq, O):
+    """the multi-GPU staging path on one GPU: partition by owner, insert part by part"""
+    import torch
+
+    batch, _ = H.synth_reads(8000, 150, 50000, seed=44, err=0.01, n_rate=0.002)
+    cpu = O.OracleDB(21, 128)
+    cpu.count_batch(batch)
+    t = torch.frombuffer(bytearray(batch), dtype=torch.uint8).cuda()
+    for n_parts in (1, 2, 8, 128):
+        src = kq.KreeqDB(21, 128)
+        keys = torch.empty(len(batch), dtype=torch.int64, device="cuda")
+        edges = torch.empty(len(batch), dtype=torch.uint8, device="cuda")
+        counts = src.emit_partitioned_dev(t.data_ptr(), len(batch), n_parts, keys.data_ptr(), edges.data_ptr(), len(batch))
+        assert counts.sum() == len(O.emit_records(21, batch)[0])
+        hk = keys.cpu().numpy().astype(np.uint64)
+        off = 0
+        dst = kq.KreeqDB(21, 128)
+        for p in range(n_parts):
+            n = int(counts[p])
+            part = hk[off:off + n]
+            owner = (part % 128) * n_parts // 128
+            assert np.all(owner == p)
+            dst.insert_records_dev(keys.data_ptr() + 8 * off, edges.data_ptr() + off, n)
+            off += n
+        dst.sync()
+        assert H.entries_equal(dst.export(), cpu.export()), n_parts
+
+
+def test_errors(kq):
+    db = kq.KreeqDB(21, 128)
+    with pytest.raises(kq.KqError):
+        db.lookup_sequence(b"ACGT" * 10, map_lo=5, map_hi=4)
+    with pytest.raises(kq.KqError):
+        db.export(0, 129)
+    other = kq.KreeqDB(31, 128)
+    with pytest.raises(kq.KqError) as e:
+        db.merge(other)
+    assert e.value.code == -7
+    db.count_batch(b"")                     # empty and shorter-than-k batches are no-ops (src/graph-builder.cpp:60)
+    db.count_batch(b"ACGTACGT")
+    assert db.summary()["distinct"] == 0
+    c, _ = db.lookup_sequence(b"ACGT")
+    assert c.tolist() == [0, 0, 0]
