@@ -1,0 +1,22 @@
+// fastx.h -- FASTA / FASTQ (optionally gzipped) reader for the host CLI.
+// Replaces the pieces of gfalibs StreamObj / loadKmers / Input::loadGenome the hot path needs
+// (reference src/input.cpp:188-286).  GFA input is out of scope.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace kqhost {
+
+struct SeqRecord { std::string header, comment, seq; };
+
+// Calls on_record for every sequence of a FASTA ('>') or FASTQ ('@') file; .gz handled by zlib.
+// FASTA sequence text has its line breaks removed (src/input.cpp:225).  Throws std::runtime_error.
+void read_fastx(const std::string& path, const std::function<void(SeqRecord&&)>& on_record);
+
+// Streams the reads of a file as batches: sequences joined by '\n' (any non-ACGT byte ends a run, so
+// k-mers never span two reads), at most ~batch_bytes each.
+void read_batches(const std::string& path, size_t batch_bytes, const std::function<void(const std::string&)>& on_batch);
+
+}  // namespace kqhost

@@ -1,0 +1,439 @@
+// kreeq (MI355X build) -- host CLI with the reference's `validate` / `union` interface.
+// Flag names, stdout blocks, exit codes and the .kreeq directory follow vgl-hub/kreeq @ 2024_08_07
+// (src/main.cpp:78-97, :220-229; src/input.cpp:76-152; src/kreeq-output.cpp:34-136;
+// src/graph-builder.cpp:288-293; src/kreeq.cpp:78-106).  All compute goes through the C ABI
+// (include/kreeq_amd.h) to the GPU; this file is plumbing: argument parsing, file formats, text.
+#include <getopt.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "fastx.h"
+#include "kreeq_amd.h"
+#include "kreeq_db.h"
+
+using namespace kqhost;
+
+namespace {
+
+const char* kVersion = "0.1.0-mi355x";
+
+struct UserInput {                       // reference UserInputKreeq (include/input.h:25-34) + gfalibs UserInput fields used
+    int mode = 0;                        // 0 validate, 1 union
+    std::string inSequence, outFile, prefix = ".", inBedInclude;
+    std::vector<std::string> inReads, kmerDB;
+    int kmerLen = 21;
+    uint32_t covCutOff = 0;
+    int kmerDepth = -1, maxSpan = 5, maxThreads = 0;
+    double maxMem = 0;
+    int device = 0;
+};
+
+int verbose_flag = 0, cmd_flag = 0;
+
+void verbose(const std::string& s) { if (verbose_flag) std::cerr << s << std::endl; }
+
+[[noreturn]] void die(const std::string& msg) {
+    fprintf(stderr, "%s\n", msg.c_str());
+    exit(EXIT_FAILURE);
+}
+void kq_or_die(int rc) { if (rc != KQ_OK) die(std::string("Error: ") + kq_last_error()); }
+
+bool is_number(const char* s) { if (!*s) return false; for (; *s; ++s) if (*s < '0' || *s > '9') return false; return true; }
+bool is_int(const char* s) { if (*s == '-' || *s == '+') ++s; return is_number(s); }
+void if_file_exists(const char* p) {
+    struct stat st;
+    if (stat(p, &st) != 0) { printf("File does not exist (%s). Terminating.\n", p); exit(EXIT_FAILURE); }
+}
+// extension after the last '.', keeping a trailing ".gz" attached ("x.gfa.gz" -> "gfa.gz")
+std::string file_ext(const std::string& path) {
+    std::string p = path;
+    std::string gz;
+    if (p.size() > 3 && p.substr(p.size() - 3) == ".gz") { gz = ".gz"; p.resize(p.size() - 3); }
+    size_t dot = p.rfind('.');
+    if (dot == std::string::npos) return "";
+    return p.substr(dot + 1) + gz;
+}
+
+void print_help() {
+    printf("kreeq [mode] -h\nfor additional help.\n");
+    printf("\nModes:\n");
+    printf("validate\n");
+    printf("union\n");
+    exit(0);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Assembly {
+    std::vector<SeqRecord> seqs;
+    std::vector<uint64_t> offset;     // start of each sequence inside `joined`
+    std::string joined;               // sequences separated by '\n' (a non-ACGT byte ends every segment)
+};
+
+void load_genome(const std::string& path, Assembly& a) {          // reference Input::loadGenome, src/input.cpp:188-308
+    std::string ext = file_ext(path);
+    if (ext.rfind("gfa", 0) == 0) die("GFA input is not supported by this build (FASTA/FASTQ only): " + path);
+    read_fastx(path, [&](SeqRecord&& r) { a.seqs.push_back(std::move(r)); });
+    size_t total = 0;
+    for (auto& s : a.seqs) total += s.seq.size() + 1;
+    a.joined.reserve(total);
+    for (auto& s : a.seqs) {
+        a.offset.push_back(a.joined.size());
+        a.joined += s.seq;
+        a.joined.push_back('\n');
+    }
+}
+
+inline bool is_base(char c) {
+    switch (c) { case 'A': case 'C': case 'G': case 'T': case 'a': case 'c': case 'g': case 't': return true; default: return false; }
+}
+// segments of one sequence = maximal runs of bases (gfalibs appendSequence splits at N runs)
+std::vector<std::pair<uint64_t, uint64_t>> segments_of(const std::string& s) {
+    std::vector<std::pair<uint64_t, uint64_t>> out;
+    for (uint64_t i = 0; i < s.size();) {
+        if (!is_base(s[i])) { ++i; continue; }
+        uint64_t j = i;
+        while (j < s.size() && is_base(s[j])) ++j;
+        out.emplace_back(i, j - i);
+        i = j;
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Engine {
+    kq_handle* h = nullptr;
+    UserInput ui;
+    int k = 21, map_count = 128;
+    Assembly genome;
+    std::vector<kq_dbgbase> per_base;     // aligned with genome.joined when a per-base writer needs it
+    uint64_t counters[3] = {0, 0, 0};
+
+    void create(uint64_t hint) { kq_or_die(kq_create(&h, ui.device, k, map_count, hint)); }
+
+    void stats() {                                                   // gfalibs stats() -> DBG::summary + DBG::DBstats
+        kq_stats st;
+        kq_or_die(kq_summary(h, &st));
+        std::cout << "DBG Summary statistics:\n"                     // src/graph-builder.cpp:288-293
+                  << "Total kmers: " << st.total << "\n"
+                  << "Unique kmers: " << st.unique << "\n"
+                  << "Distinct kmers: " << st.distinct << "\n"
+                  << "Missing kmers: " << st.missing << "\n"
+                  << "Total edges: " << st.edges << "\n";
+    }
+
+    static double error_rate(uint64_t missing, uint64_t total, int k) {          // src/kreeq.cpp:36-40
+        return 1 - pow(1 - (double)missing / total, (double)1 / k);
+    }
+
+    void validate_sequences(bool want_per_base) {                    // DBG::validateSequences, src/kreeq.cpp:47-108
+        if (ui.inSequence.empty()) return;
+        verbose("Validating sequence");
+        if (want_per_base) per_base.assign(genome.joined.size(), kq_dbgbase{});
+        kq_or_die(kq_lookup_sequence(h, genome.joined.data(), genome.joined.size(), ui.covCutOff, 0, (uint16_t)map_count,
+                                     want_per_base ? per_base.data() : nullptr, counters));
+        if (ui.outFile.find(".") != std::string::npos || ui.outFile == "") {
+            const uint64_t missing = counters[0], total = counters[1], edge_missing = counters[2];
+            std::cout << "Missing" << "\t" << "Total" << "\t" << "QV" << "\t" << "Error" << "\t" << "k" << "\t" << "Method" << std::endl;
+            double merquryError = error_rate(missing, total, k), merquryQV = -10 * log10(merquryError);
+            std::cout << missing << "\t" << total << "\t" << merquryQV << "\t" << merquryError << "\t" << std::to_string(k) << "\t"
+                      << "Merqury" << std::endl;
+            double kreeqError = error_rate(missing + edge_missing, total, k), kreeqQV = -10 * log10(kreeqError);
+            std::cout << missing + edge_missing << "\t" << total << "\t" << kreeqQV << "\t" << kreeqError << "\t" << std::to_string(k)
+                      << "\t" << "Kreeq" << std::endl;
+        }
+    }
+
+    void write_kreeq_db(const std::string& dir) {
+        uint64_t n = 0;
+        kq_or_die(kq_export(h, 0, (uint16_t)map_count, nullptr, 0, &n));
+        std::vector<kq_entry> entries((size_t)n);
+        if (n) kq_or_die(kq_export(h, 0, (uint16_t)map_count, entries.data(), n, &n));
+        write_db(dir, k, map_count, entries);
+    }
+
+    // .kwig (src/kreeq-output.cpp:243-303) and .bkwig (:305-399)
+    void write_kwig(const std::string& path) {
+        std::ofstream ofs(path);
+        ofs << std::to_string(k) << "\n";
+        for (size_t s = 0; s < genome.seqs.size(); ++s) {
+            for (auto& seg : segments_of(genome.seqs[s].seq)) {
+                ofs << "fixedStep chrom=" << genome.seqs[s].header << " start=" << seg.first << " step=1" << "\n";
+                const kq_dbgbase* b = per_base.data() + genome.offset[s] + seg.first;
+                for (uint64_t i = 0; i < seg.second; ++i)
+                    ofs << std::to_string(b[i].cov) << "," << std::to_string(b[i].isFw ? b[i].fw : b[i].bw) << ","
+                        << std::to_string(b[i].isFw ? b[i].bw : b[i].fw) << "\n";
+            }
+        }
+    }
+    void write_bkwig(const std::string& path) {
+        std::ofstream ofs(path, std::ios::trunc | std::ios::out | std::ios::binary);
+        uint8_t k8 = (uint8_t)k;
+        ofs.write((const char*)&k8, 1);
+        uint32_t nPaths = (uint32_t)genome.seqs.size();
+        ofs.write((const char*)&nPaths, 4);
+        std::vector<std::vector<std::pair<uint64_t, uint64_t>>> segs;
+        for (auto& s : genome.seqs) segs.push_back(segments_of(s.seq));
+        for (size_t s = 0; s < genome.seqs.size(); ++s) {                            // writeIndex :305-355
+            uint16_t hl = (uint16_t)genome.seqs[s].header.size();
+            ofs.write((const char*)&hl, 2);
+            ofs << genome.seqs[s].header;
+            uint32_t nc = (uint32_t)segs[s].size();
+            ofs.write((const char*)&nc, 4);
+            for (auto& seg : segs[s]) {
+                uint8_t step = 1;
+                ofs.write((const char*)&seg.first, 8);
+                ofs.write((const char*)&seg.second, 8);
+                ofs.write((const char*)&step, 1);
+            }
+        }
+        for (size_t s = 0; s < genome.seqs.size(); ++s)
+            for (auto& seg : segs[s]) {
+                const kq_dbgbase* b = per_base.data() + genome.offset[s] + seg.first;
+                for (uint64_t i = 0; i < seg.second; ++i) {
+                    ofs.write((const char*)&b[i].cov, 4);
+                    ofs.write((const char*)(b[i].isFw ? &b[i].fw : &b[i].bw), 4);
+                    ofs.write((const char*)(b[i].isFw ? &b[i].bw : &b[i].fw), 4);
+                }
+            }
+    }
+    void write_hist(const std::string& path) {                       // gfalibs printHist (format not pinned by any fixture)
+        uint64_t n = 0;
+        kq_or_die(kq_histogram(h, nullptr, nullptr, 0, &n));
+        std::vector<uint64_t> cov((size_t)n), cnt((size_t)n);
+        if (n) kq_or_die(kq_histogram(h, cov.data(), cnt.data(), n, &n));
+        std::ofstream ofs(path);
+        for (uint64_t i = 0; i < n; ++i) ofs << cov[i] << "\t" << cnt[i] << "\n";
+    }
+
+    void report() {                                                  // DBG::report, src/kreeq-output.cpp:34-136
+        std::string ext = "stdout";
+        if (ui.outFile != "") ext = file_ext("." + ui.outFile);
+        if (ui.outFile.find(".") != std::string::npos || ui.outFile == "" || ext == "kreeq") stats();
+        verbose("Writing ouput: " + ui.outFile);
+        const bool per_base_out = (ext == "kwig" || ext == "bkwig");
+        if (ext == "gfa" || ext == "gfa2" || ext == "gfa.gz" || ext == "gfa2.gz" || ext == "vcf")
+            die("Error: ." + ext + " output (variant search) is not supported by this build");
+        if (ext != "kreeq" && ext != "hist" && ui.mode == 0) validate_sequences(per_base_out);
+        if (ext == "kreeq") write_kreeq_db(ui.outFile);
+        else if (ext == "kwig") write_kwig(ui.outFile);
+        else if (ext == "bkwig") write_bkwig(ui.outFile);
+        else if (ext == "hist") write_hist(ui.outFile);
+    }
+};
+
+uint64_t file_size(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0; }
+
+int run(UserInput& ui) {
+    Engine e;
+    e.ui = ui;
+    if (ui.outFile.find(".kreeq") != std::string::npos) e.ui.prefix = ui.outFile;        // src/input.cpp:78-79
+    switch (ui.mode) {
+        case 0: {                                                    // src/input.cpp:86-118
+            if (!ui.inReads.empty()) {
+                e.k = ui.kmerLen;
+                uint64_t bytes = 0;
+                for (auto& f : ui.inReads) bytes += file_size(f) * (file_ext(f).find("gz") != std::string::npos ? 4 : 1);
+                e.create(std::min<uint64_t>(bytes / 2 + (1 << 20), 1ull << 31));
+                verbose("Loading input reads.");
+                for (auto& f : ui.inReads)
+                    read_batches(f, (size_t)256 << 20, [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
+                verbose("Reads loaded.");
+            } else {                                                 // Input::loadGraph, src/input.cpp:56-74
+                if (ui.kmerDB.size() > 1) die("More than one DBG database provided. Merge them first. Exiting.");
+                if (ui.kmerDB.empty()) die("Cannot load DBG input. Exiting.");
+                std::vector<kq_entry> entries;
+                DbIndex idx;
+                read_db(ui.kmerDB[0], entries, &idx);
+                verbose("Overriding default kmer length (" + std::to_string(ui.kmerLen) + ") with DB kmer length (" + std::to_string(idx.k) + ").");
+                e.k = idx.k; e.map_count = idx.map_count;
+                e.create(entries.size() + 1024);
+                kq_or_die(kq_import(e.h, entries.data(), entries.size()));
+            }
+            if (!ui.inSequence.empty()) {
+                verbose("Loading input sequences");
+                load_genome(ui.inSequence, e.genome);
+                verbose("Sequences loaded");
+            }
+            e.report();
+            break;
+        }
+        case 1: {                                                    // src/input.cpp:119-152
+            verbose("Merging input databases.");
+            int k = 0, map_count = 128;
+            for (auto& db : ui.kmerDB) {
+                DbIndex idx = read_index(db);
+                if (k == 0) { k = idx.k; map_count = idx.map_count; }
+                if (k != idx.k) { fprintf(stderr, "Cannot merge databases with different kmer length.\n"); exit(1); }
+            }
+            if (k == 0 || k > 32) { fprintf(stderr, "Invalid kmer length.\n"); exit(1); }
+            e.k = k; e.map_count = map_count;
+            std::vector<std::vector<kq_entry>> all(ui.kmerDB.size());
+            uint64_t total = 0;
+            for (size_t i = 0; i < ui.kmerDB.size(); ++i) { read_db(ui.kmerDB[i], all[i]); total += all[i].size(); }
+            e.create(total + 1024);
+            verbose("DBG object generated. Merging.");
+            for (auto& v : all) kq_or_die(kq_import(e.h, v.data(), v.size()));            // DBG::kunion: import == add
+            e.report();
+            break;
+        }
+        default:
+            fprintf(stderr, "Invalid mode.\n");
+            exit(1);
+    }
+    kq_destroy(e.h);
+    return EXIT_SUCCESS;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    UserInput ui;
+    if (argc == 1 || argc == 2) print_help();
+    std::string mode = argv[1];
+    if (mode == "dbtool") {           // host-only helper (no GPU): `dbtool dump <db>` | `dbtool rewrite <in> <out>`
+        try {
+            std::vector<kq_entry> entries;
+            DbIndex idx;
+            if (argc == 4 && std::string(argv[2]) == "dump") {
+                read_db(argv[3], entries, &idx);
+                printf("#k=%d map_count=%d columns: map key fw0 fw1 fw2 fw3 bw0 bw1 bw2 bw3 cov hc\n", idx.k, idx.map_count);
+                std::sort(entries.begin(), entries.end(), [](const kq_entry& a, const kq_entry& b) { return a.key < b.key; });
+                for (auto& e : entries)
+                    printf("%llu %llu %u %u %u %u %u %u %u %u %u %u\n", (unsigned long long)(e.key % (uint64_t)idx.map_count),
+                           (unsigned long long)e.key, e.fw[0], e.fw[1], e.fw[2], e.fw[3], e.bw[0], e.bw[1], e.bw[2], e.bw[3], e.cov, e.hc);
+                return EXIT_SUCCESS;
+            }
+            if (argc == 5 && std::string(argv[2]) == "rewrite") {
+                read_db(argv[3], entries, &idx);
+                write_db(argv[4], idx.k, idx.map_count, entries);
+                return EXIT_SUCCESS;
+            }
+        } catch (const std::exception& ex) { fprintf(stderr, "%s\n", ex.what()); return EXIT_FAILURE; }
+        fprintf(stderr, "usage: kreeq dbtool dump <db.kreeq> | rewrite <in.kreeq> <out.kreeq>\n");
+        return EXIT_FAILURE;
+    }
+    if (mode == "validate") ui.mode = 0;
+    else if (mode == "union") ui.mode = 1;
+    else if (mode == "subgraph") { fprintf(stderr, "mode subgraph is not part of this build (validate / union only)\n"); return EXIT_FAILURE; }
+    else { fprintf(stderr, "mode %s does not exist. Terminating\n", argv[1]); return EXIT_FAILURE; }
+
+    if (ui.mode == 0) {
+        static struct option long_options[] = {                      // src/main.cpp:78-97
+            {"coverage-cutoff", required_argument, 0, 'c'}, {"database", required_argument, 0, 'd'},
+            {"input-positions", required_argument, 0, 'p'}, {"input-sequence", required_argument, 0, 'f'},
+            {"kmer-length", required_argument, 0, 'k'}, {"search-depth", required_argument, 0, 0},
+            {"max-span", required_argument, 0, 0}, {"out-format", required_argument, 0, 'o'},
+            {"input-reads", required_argument, 0, 'r'}, {"tmp-prefix", required_argument, 0, 't'},
+            {"max-memory", required_argument, 0, 'm'}, {"threads", required_argument, 0, 'j'},
+            {"device", required_argument, 0, 0},
+            {"verbose", no_argument, &verbose_flag, 1}, {"cmd", no_argument, &cmd_flag, 1},
+            {"version", no_argument, 0, 'v'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+        for (;;) {
+            int option_index = 0;
+            int c = getopt_long(argc, argv, "-:c:d:f:k:o:p:r:t:m:j:vh", long_options, &option_index);
+            if (c == -1) break;
+            switch (c) {
+                case ':': fprintf(stderr, "option -%c is missing a required argument\n", optopt); return EXIT_FAILURE;
+                case 0:
+                    if (strcmp(long_options[option_index].name, "search-depth") == 0) ui.kmerDepth = atoi(optarg);
+                    if (strcmp(long_options[option_index].name, "max-span") == 0) ui.maxSpan = atoi(optarg);
+                    if (strcmp(long_options[option_index].name, "device") == 0) ui.device = atoi(optarg);
+                    break;
+                case 'c':
+                    if (!is_number(optarg)) { fprintf(stderr, "input '%s' to option -%c must be a number\n", optarg, optopt); return EXIT_FAILURE; }
+                    ui.covCutOff = (uint32_t)atoi(optarg);
+                    break;
+                case 'd': if_file_exists(optarg); ui.kmerDB.push_back(optarg); break;
+                case 'f': if_file_exists(optarg); ui.inSequence = optarg; break;
+                case 'k':
+                    if (!is_number(optarg)) { fprintf(stderr, "input '%s' to option -%c must be a number\n", optarg, optopt); return EXIT_FAILURE; }
+                    ui.kmerLen = atoi(optarg);
+                    break;
+                case 'j': ui.maxThreads = atoi(optarg); break;
+                case 'o': ui.outFile = optarg; break;
+                case 'p': if_file_exists(optarg); ui.inBedInclude = optarg; break;
+                case 'r':                                            // consumes several files, src/main.cpp:169-180
+                    optind--;
+                    for (; optind < argc && *argv[optind] != '-' && !is_int(argv[optind]); optind++) {
+                        if_file_exists(argv[optind]);
+                        ui.inReads.push_back(argv[optind]);
+                    }
+                    break;
+                case 't': ui.prefix = optarg; break;
+                case 'm': ui.maxMem = atof(optarg); break;
+                case 'v': printf("kreeq v%s (MI355X build)\n", kVersion); exit(0);
+                case 'h':
+                    printf("kreeq [command]\n\nOptions:\n");
+                    printf("\t-c --coverage-cutoff coverage cutoff.\n");
+                    printf("\t-d --database kreeq database to load.\n");
+                    printf("\t-f --input-sequence sequence input file (fasta,fastq).\n");
+                    printf("\t-r --input-reads read input files (fastq).\n");
+                    printf("\t-k --kmer-length length of kmers.\n");
+                    printf("\t-o --out-format supported extensions:\n");
+                    printf("\t\t .kreeq dumps hashmaps to file for reuse; .kwig .bkwig per-base tables; .hist coverage histogram.\n");
+                    printf("\t-t --tmp-prefix prefix to temporary directory (unused: the table lives in HBM).\n");
+                    printf("\t-m --max-memory accepted for compatibility.\n");
+                    printf("\t-j --threads <n> accepted for compatibility.\n");
+                    printf("\t--device <n> GPU to use (default 0).\n");
+                    printf("\t-v --version software version.\n");
+                    printf("\t--cmd print $0 to stdout.\n");
+                    exit(0);
+                default: break;                                      // positional arguments are ignored like the reference
+            }
+        }
+        if (ui.kmerLen < 2 || ui.kmerLen > 32) { fprintf(stderr, "Invalid kmer length.\n"); return EXIT_FAILURE; }
+    } else {
+        static struct option long_options[] = {                      // src/main.cpp:220-229
+            {"databases", required_argument, 0, 'd'}, {"out-format", required_argument, 0, 'o'},
+            {"threads", required_argument, 0, 'j'}, {"device", required_argument, 0, 0},
+            {"verbose", no_argument, &verbose_flag, 1}, {"cmd", no_argument, &cmd_flag, 1},
+            {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+        for (;;) {
+            int option_index = 1;
+            int c = getopt_long(argc, argv, "-:d:j:o:h", long_options, &option_index);
+            if (c == -1) break;
+            switch (c) {
+                case ':': fprintf(stderr, "option -%c is missing a required argument\n", optopt); return EXIT_FAILURE;
+                case 0: if (strcmp(long_options[option_index].name, "device") == 0) ui.device = atoi(optarg); break;
+                case 'd':
+                    optind--;
+                    for (; optind < argc && *argv[optind] != '-' && !is_int(argv[optind]); optind++) {
+                        if_file_exists(argv[optind]);
+                        ui.kmerDB.push_back(argv[optind]);
+                    }
+                    break;
+                case 'j': ui.maxThreads = atoi(optarg); break;
+                case 'o': ui.outFile = optarg; break;
+                case 'h':
+                    printf("kreeq union [options]\n\nOptions:\n");
+                    printf("\t-d --databases DBG databases to merge.\n");
+                    printf("\t-j --threads <n> accepted for compatibility.\n");
+                    printf("\t-o --out-format generates various kinds of outputs (currently supported: .kreeq).\n");
+                    printf("\t--cmd print $0 to stdout.\n");
+                    exit(0);
+                default: break;
+            }
+        }
+        if (ui.kmerDB.size() < 2) { fprintf(stderr, "At least two databases required (-d).\n"); return EXIT_FAILURE; }   // src/main.cpp:290-293
+    }
+    if (cmd_flag) {
+        for (int i = 0; i < argc; ++i) printf("%s ", argv[i]);
+        printf("\n");
+    }
+    try {
+        return run(ui);
+    } catch (const std::exception& ex) {
+        fprintf(stderr, "%s\n", ex.what());
+        return EXIT_FAILURE;
+    }
+}

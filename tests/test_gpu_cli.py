@@ -1,0 +1,92 @@
+"""Replays the reference's golden-stdout tests (validateFiles/*.tst, harness semantics of reference
+src/validate.cpp:52-122) against OUR `kreeq` CLI on the GPU, plus .kreeq / .bkwig file round trips."""
+import os
+import subprocess
+
+import pytest
+
+from kreeq_amd import build
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+VALIDATE_TESTS = [i for i in range(0, 35) if not 15 <= i <= 19]   # 15-19: GFA assembly input (out of scope)
+
+
+@pytest.fixture(scope="module")
+def cli():
+    assert os.path.exists(build.LIB), "libkreeq_amd.so must be built in-tree"
+    return build.build_cli()
+
+
+def remap(argv, golden_dbs):
+    out = []
+    for a in argv[1:]:
+        if a.startswith("testFiles/") and a.endswith(".kreeq"):
+            out.append(os.path.join(golden_dbs, os.path.basename(a)))
+        elif a.startswith("testFiles/"):
+            out.append(H.golden_input(a))
+        else:
+            out.append(a)
+    return out
+
+
+def run(cli, args, cwd=None):
+    p = subprocess.run([cli] + args, capture_output=True, text=True, cwd=cwd, timeout=300)
+    assert p.returncode == 0, p.stderr
+    return p.stdout.split("\n")
+
+
+@pytest.mark.parametrize("idx", VALIDATE_TESTS + [35])
+def test_tst_replay(cli, golden_dbs, idx):
+    argv, expected = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", f"test.{idx}.tst"))
+    got = run(cli, remap(argv, golden_dbs))
+    while got and got[-1] == "":
+        got.pop()
+    assert got == expected
+
+
+def test_db_write_then_validate(cli, tmp_path, golden_dbs):
+    """validate -r reads -o db.kreeq ; validate -f asm -d db.kreeq == validate -f asm -r reads"""
+    from tests.golden.make_golden import decode_db
+
+    db = str(tmp_path / "r1.kreeq")
+    out1 = run(cli, ["validate", "-r", H.golden_input("random1.fastq"), "-o", db])
+    _, exp = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.0.tst"))
+    assert [l for l in out1 if l] == exp[:6]                      # stats only, no QV table
+    assert decode_db(db) == decode_db(os.path.join(golden_dbs, "test1.kreeq"))
+    out2 = run(cli, ["validate", "-f", H.golden_input("random1.fasta"), "-d", db])
+    assert [l for l in out2 if l] == exp
+    # union of our own databases, written to disk and validated from disk
+    db2, dbu = str(tmp_path / "r2.kreeq"), str(tmp_path / "u.kreeq")
+    run(cli, ["validate", "-r", H.golden_input("random2.fastq"), "-o", db2])
+    outu = run(cli, ["union", "-d", db, db2, "-o", dbu])
+    _, exp35 = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.35.tst"))
+    assert [l for l in outu if l] == exp35
+    _, exp3 = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.3.tst"))
+    out3 = run(cli, ["validate", "-f", H.golden_input("random1.fasta"), "-d", dbu])
+    assert [l for l in out3 if l] == exp3
+
+
+@pytest.mark.parametrize("asm,reads,bkwig", [("repeat1.fasta", "repeat1.fastq", "decompressor2.bkwig"),
+                                            ("decompressor1.fasta", "random1.fastq", "decompressor1.bkwig")])
+def test_bkwig_bytes(cli, tmp_path, asm, reads, bkwig):
+    """the per-base binary table is byte-identical to the reference's fixture"""
+    out = str(tmp_path / "o.bkwig")
+    run(cli, ["validate", "-f", H.golden_input(asm), "-r", H.golden_input(reads), "-o", out])
+    assert open(out, "rb").read() == open(H.golden_input(bkwig), "rb").read()
+
+
+def test_kwig_text(cli, tmp_path):
+    """.kwig is the text twin; the reference's decompressor 'inflate' golden (test.49) has the same body"""
+    out = str(tmp_path / "o.kwig")
+    run(cli, ["validate", "-f", H.golden_input("repeat1.fasta"), "-r", H.golden_input("repeat1.fastq"), "-o", out])
+    _, exp = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.49.tst"))
+    assert open(out).read().split("\n")[:len(exp)] == exp
+
+
+def test_cli_errors(cli):
+    p = subprocess.run([cli, "union", "-d", "x"], capture_output=True, text=True)
+    assert p.returncode != 0
+    p = subprocess.run([cli, "bogus", "-h"], capture_output=True, text=True)
+    assert p.returncode != 0 and "does not exist" in p.stderr
