@@ -1,0 +1,111 @@
+"""world_size-2 (and 3) gloo tests of the bucket-sharded count path (kreeq_amd/dist.py) on CPU.
+The routing code under test is the product's; the per-rank compute engine is a host stand-in built
+on the oracle (test infrastructure), exactly the interface GpuEngine implements."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import helpers as H
+
+
+class HostEngine:
+    def __init__(self, k, map_count):
+        from oracle import oracle as O
+
+        self.O, self.k, self.map_count = O, k, map_count
+        self.db = O.OracleDB(k, map_count)
+
+    def emit_partitioned(self, bases, n_parts):
+        from kreeq_amd.dist import owner_of
+
+        keys, edges = self.O.emit_records(self.k, bases.numpy().tobytes())
+        owner = owner_of(keys, n_parts, self.map_count)
+        order = np.argsort(owner, kind="stable")
+        counts = np.bincount(owner, minlength=n_parts).astype(np.int64)
+        return torch.from_numpy(keys[order].astype(np.int64)), torch.from_numpy(edges[order]), counts
+
+    def insert(self, keys, edges):
+        self.db.insert_records(keys.numpy().astype(np.uint64), edges.numpy())
+
+    def lookup(self, bases, map_lo, map_hi, cov_cutoff=0):
+        c, _ = self.db.validate_sequence(bases.numpy().tobytes(), cov_cutoff=cov_cutoff, map_lo=map_lo, map_hi=map_hi)
+        return torch.from_numpy(c.astype(np.int64))
+
+    def summary_vector(self):
+        s = self.db.summary()
+        return torch.tensor([s["total"], s["unique"], s["distinct"], s["edges"]], dtype=torch.int64)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, k, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kreeq_amd.dist import ShardedCounter, owner_range
+
+        sc = ShardedCounter(HostEngine(k, 128), k, 128)
+        assert (sc.map_lo, sc.map_hi) == owner_range(rank, world, 128)
+        # two batches per rank, different reads on every rank (seed depends on rank)
+        for b in range(2):
+            batch, _ = H.synth_reads(1500, 100, 30000, seed=1000 + 10 * rank + b, err=0.01, n_rate=0.003)
+            sc.count_batch(torch.frombuffer(bytearray(batch), dtype=torch.uint8))
+        _, genome = H.synth_reads(10, 100, 30000, seed=1000)          # same genome (seed of rank 0, batch 0)
+        ctr = sc.validate(torch.frombuffer(bytearray(genome), dtype=torch.uint8))
+        summ = sc.summary()
+        ent = sc.engine.db.export()
+        m = ent["key"] % 128
+        assert np.all((m >= sc.map_lo) & (m < sc.map_hi))                # a rank holds only the maps it owns
+        np.save(os.path.join(out_dir, f"entries_{rank}.npy"), ent)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "ctr.npy"), ctr)
+            np.save(os.path.join(out_dir, "summ.npy"), np.array([summ[f] for f in ("total", "unique", "distinct", "missing", "edges")], dtype=np.uint64))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k", [(2, 21), (3, 31)])
+def test_sharded_count_matches_single(tmp_path, world, k):
+    from oracle import oracle as O
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, k, str(tmp_path)), nprocs=world, join=True)
+    ref = O.OracleDB(k, 128)
+    for rank in range(world):
+        for b in range(2):
+            batch, _ = H.synth_reads(1500, 100, 30000, seed=1000 + 10 * rank + b, err=0.01, n_rate=0.003)
+            ref.count_batch(batch)
+    _, genome = H.synth_reads(10, 100, 30000, seed=1000)
+    parts = [np.load(os.path.join(tmp_path, f"entries_{r}.npy")) for r in range(world)]
+    merged = np.concatenate(parts)
+    merged = merged[np.argsort(merged["key"])]
+    assert H.entries_equal(merged, ref.export())
+    c, _ = ref.validate_sequence(genome)
+    assert np.load(os.path.join(tmp_path, "ctr.npy")).tolist() == c.tolist()
+    s = ref.summary()
+    assert np.load(os.path.join(tmp_path, "summ.npy")).tolist() == [s[f] for f in ("total", "unique", "distinct", "missing", "edges")]
+
+
+def test_owner_mapping_is_a_partition():
+    from kreeq_amd.dist import owner_of, owner_range
+
+    for world in (1, 2, 3, 5, 8, 128):
+        keys = np.arange(0, 5000, dtype=np.uint64) * np.uint64(2654435761)
+        own = owner_of(keys, world, 128)
+        seen = np.zeros(128, dtype=int)
+        for r in range(world):
+            lo, hi = owner_range(r, world, 128)
+            seen[lo:hi] += 1
+            m = keys[own == r] % np.uint64(128)
+            assert np.all((m >= lo) & (m < hi))
+        assert np.all(seen == 1)
