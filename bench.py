@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=N_READS, help="reads per GPU (default = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--capacity", type=int, default=24_000_000,
+                    help="expected distinct k-mers per GPU (table = capacity/0.6 slots; the workload has 17.7 M)")
+    ap.add_argument("--path", choices=["auto", "direct", "partitioned"], default="auto")
     args = ap.parse_args()
 
     import torch
@@ -70,7 +73,9 @@ def main():
     # recorded on the same stream, so they bracket exactly the kernels of one step
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    engine = GpuEngine(K, 128, local_rank, capacity_hint=int(kmers_per_rank * 1.05))
+    engine = GpuEngine(K, 128, local_rank, capacity_hint=args.capacity)
+    engine.db.set_option("trust_capacity", 1)     # the hint is an upper bound of the distinct k-mers (jellyfish -s style)
+    engine.db.set_option("count_path", args.path)
     counter = ShardedCounter(engine, K, 128)
 
     def step():
@@ -121,10 +126,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"synthetic {args.reads} x {READ_LEN} bp reads per GPU, k={K}, count-only (configs[1])",
-                       "genome_bp": GENOME_LEN, "error_rate": ERR, "sharding": f"bucket x{world}" if world > 1 else "none"},
+                       "genome_bp": GENOME_LEN, "error_rate": ERR, "table_capacity_kmers": args.capacity, "count_path": args.path, "sharding": f"bucket x{world}" if world > 1 else "none"},
             "total_kmers_per_step": kmers_per_rank * world, "distinct_kmers": summ["distinct"],
             "distinct_kmers_per_s": summ["distinct"] * args.steps / dt,
-            "roofline": {"bound": "hbm", "kernel": "k_count_direct" if world == 1 else "k_part_scatter+k_insert_records",
+            "roofline": {"bound": "hbm", "kernel": ("count_batch: k_p1_hist+k_p1_scatter+k_p2_hist+k_p2_scatter+k_count_regions" if args.path != "direct"
+                                                    else "k_count_direct") if world == 1 else "k_part_scatter+all_to_all+k_insert_records",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": kern_ms},
         }

@@ -97,6 +97,14 @@ int  kq_clear(kq_handle* h);
 /* Make the handle enqueue on a caller-owned hipStream_t (NULL = the handle's own stream). */
 int  kq_set_stream(kq_handle* h, void* hip_stream);
 void* kq_get_stream(kq_handle* h);
+/* Tuning knobs (no reference counterpart).
+ *   KQ_OPT_TRUST_CAPACITY  value != 0: capacity_hint given to kq_create is an upper bound of the
+ *                          distinct k-mers the table will ever hold, so batches do not pre-grow the
+ *                          table for their worst case (all k-mers new).  If the bound is wrong a
+ *                          table region overflows and the next sync returns KQ_ERR_TABLE_FULL.
+ *   KQ_OPT_COUNT_PATH      0 = auto, 1 = direct (global atomics), 2 = partitioned (LDS regions; k <= 28) */
+enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2 };
+int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_sync(kq_handle* h);
 int  kq_get_info(kq_handle* h, kq_info* out);
 const char* kq_last_error(void);

@@ -12,7 +12,7 @@ ENTRY_DTYPE = np.dtype([("key", "<u8"), ("fw", "<u4", 4), ("bw", "<u4", 4), ("co
 DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw", "u1"), ("pad", "u1", 3)])
 
 # every symbol include/kreeq_amd.h declares
-SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_get_info", "kq_last_error",
+SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_get_info", "kq_last_error",
            "kq_abi_version", "kq_device_available", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
            "kq_emit_partitioned_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
            "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_merge", "kq_import", "kq_export"]
@@ -80,6 +80,7 @@ def load():
     L.kq_destroy.restype = None
     L.kq_clear.argtypes = [vp]
     L.kq_set_stream.argtypes = [vp, vp]
+    L.kq_set_option.argtypes = [vp, ci, C.c_int64]
     L.kq_get_stream.argtypes = [vp]
     L.kq_get_stream.restype = vp
     L.kq_sync.argtypes = [vp]
@@ -140,6 +141,13 @@ class KreeqDB:
 
     def sync(self):
         _check(load().kq_sync(self._h))
+
+    def set_option(self, option, value):
+        """option: 'trust_capacity' | 'count_path' ('auto'|'direct'|'partitioned')"""
+        opt = {"trust_capacity": 1, "count_path": 2}[option]
+        if option == "count_path":
+            value = {"auto": 0, "direct": 1, "partitioned": 2}[value]
+        _check(load().kq_set_option(self._h, opt, int(value)))
 
     def clear(self):
         _check(load().kq_clear(self._h))

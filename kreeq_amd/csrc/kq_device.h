@@ -276,6 +276,33 @@ __device__ __forceinline__ void tile_lane_scan(const uint32_t* s_codes, const ui
     }
 }
 
+// same walk, but f(i, valid, fw, prev, next) is called for EVERY one of the 16 starts with the
+// compile-time index i, so callers can fill register arrays with static indexing
+template <class F>
+__device__ __forceinline__ void tile_lane_scan_all(const uint32_t* s_codes, const uint32_t* s_inv, int k, F&& f) {
+    const int tid = threadIdx.x;
+    const bool lane_has_work = tid < TILE_STARTS / 16;
+    const int t = lane_has_work ? tid : 0;
+    const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+    const uint64_t wmask = (1ull << k) - 1;
+    const uint32_t c0 = s_codes[t], c1 = s_codes[t + 1], c2 = s_codes[t + 2], c3 = s_codes[t + 3];
+    const uint32_t m0 = s_inv[t];
+    const uint64_t ms = (uint64_t)s_inv[t + 1] | ((uint64_t)s_inv[t + 2] << 16) | ((uint64_t)s_inv[t + 3] << 32);
+    const uint64_t lo = (uint64_t)c1 | ((uint64_t)c2 << 32);
+    const uint64_t hi = (uint64_t)c3;
+    uint32_t prev = (m0 >> 15) ? 4u : (c0 >> 30);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t fw = ((i == 0) ? lo : ((lo >> (2 * i)) | (hi << (64 - 2 * i)))) & kmask;
+        const bool valid = lane_has_work && (((ms >> i) & wmask) == 0);
+        const int np = i + k;
+        uint32_t next = (np < 32) ? (uint32_t)(lo >> (2 * np)) & 3u : (uint32_t)(hi >> (2 * (np - 32))) & 3u;
+        if ((ms >> np) & 1) next = 4u;
+        f(i, valid, fw, prev, next);
+        prev = ((ms >> i) & 1) ? 4u : ((uint32_t)(lo >> (2 * i)) & 3u);
+    }
+}
+
 // number of valid k-mer starts among this lane's 16
 __device__ __forceinline__ uint32_t tile_lane_count(const uint32_t* s_inv, int k) {
     const int tid = threadIdx.x;

@@ -1,0 +1,107 @@
+// kq_partition.h -- partitioned count path: records are routed to the table region that owns their
+// key, then one workgroup per region applies them inside LDS.  No global atomics per k-mer.
+//
+//   P1  k_p1_hist / k_p1_scatter   bases  -> 8-B records grouped by COARSE bucket (= region >> g_shift)
+//   P2  k_p2_hist / k_p2_scatter   coarse -> records grouped by REGION
+//   P3  k_count_regions            per region: 96 KiB slot image in LDS, ds_* atomics, stream back
+//
+// Both splits are workgroup-level multisplits: a tile of <= 4096 records is ranked with LDS
+// atomics, staged bucket-contiguous in LDS and copied out as coalesced runs; the only global
+// atomics are one reservation per (tile, non-empty bucket).
+//
+// Record (k <= 28): key in bits 0..2k-1, reference edge byte (include/kreeq.h:6-18) in bits 56..63.
+#pragma once
+#include "kq_device.h"
+
+namespace kq {
+
+constexpr int MS_THREADS = 256;
+constexpr int MS_ITEMS = 16;
+constexpr int MS_TILE = MS_THREADS * MS_ITEMS;   // 4096 records per multisplit round
+constexpr int NB_MAX = 1024;                     // max fan-out of one split
+constexpr uint32_t BIN_NONE = 0xFFFFu;
+constexpr int REC_EDGE_SHIFT = 56;
+constexpr int PART_MAX_K = 28;
+
+struct PartCfg {
+    uint64_t n_regions;   // R
+    uint32_t g_shift;     // coarse bucket = region >> g_shift
+    uint32_t n_coarse;    // ceil(R / 2^g_shift) <= NB_MAX ; fan-out of P2 = 2^g_shift <= NB_MAX
+};
+
+__device__ __forceinline__ uint64_t rec_pack(uint64_t key, uint32_t edge_byte) { return key | ((uint64_t)edge_byte << REC_EDGE_SHIFT); }
+__device__ __forceinline__ uint64_t rec_key(uint64_t rec) { return rec & ((1ull << REC_EDGE_SHIFT) - 1); }
+__device__ __forceinline__ uint32_t rec_edge(uint64_t rec) { return (uint32_t)(rec >> REC_EDGE_SHIFT); }
+__device__ __forceinline__ uint64_t region_id(uint64_t key, uint64_t n_regions) { return __umul64hi(mix64(key), n_regions); }
+
+struct MsShared {
+    uint64_t stage[MS_TILE];                 // 32 KiB
+    uint16_t sbin[MS_TILE];                  //  8 KiB
+    uint32_t hist[NB_MAX];                   //  4 KiB
+    uint32_t loff[NB_MAX];                   //  4 KiB
+    unsigned long long gbase[NB_MAX];        //  8 KiB
+    uint32_t wave_sum[MS_THREADS / 64];
+    uint32_t total;
+};
+
+// exclusive scan of s.hist[0..nb) into s.loff, total into s.total.  nb <= NB_MAX = 4 * MS_THREADS.
+__device__ __forceinline__ void ms_scan(MsShared& s, uint32_t nb) {
+    const int tid = threadIdx.x;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { uint32_t b = 4 * tid + j; v[j] = (b < nb) ? s.hist[b] : 0; sum += v[j]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t n = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += n; }
+    if ((tid & 63) == 63) s.wave_sum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += s.wave_sum[w];
+    uint32_t run = base + incl - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { uint32_t b = 4 * tid + j; if (b < nb) s.loff[b] = run; run += v[j]; }
+    if (tid == MS_THREADS - 1) s.total = run;
+    __syncthreads();
+}
+
+// One multisplit round: every thread brings up to 16 records with their bins (BIN_NONE = no record).
+// Space in `out` is reserved per bin with one atomicAdd on cursors[bin]; records of a bin land
+// contiguously there.  All threads of the block must call it.
+__device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&rec)[MS_ITEMS], const uint32_t (&bin)[MS_ITEMS], uint32_t nb,
+                                                 unsigned long long* __restrict__ cursors, uint64_t* __restrict__ out) {
+    const int tid = threadIdx.x;
+    for (uint32_t b = tid; b < nb; b += MS_THREADS) s.hist[b] = 0;
+    __syncthreads();
+    uint32_t rank[MS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < MS_ITEMS; ++i) rank[i] = (bin[i] != BIN_NONE) ? atomicAdd(&s.hist[bin[i]], 1u) : 0u;
+    __syncthreads();
+    ms_scan(s, nb);
+    for (uint32_t b = tid; b < nb; b += MS_THREADS) {
+        const uint32_t c = s.hist[b];
+        if (c) s.gbase[b] = atomicAdd(&cursors[b], (unsigned long long)c);
+    }
+#pragma unroll
+    for (int i = 0; i < MS_ITEMS; ++i)
+        if (bin[i] != BIN_NONE) {
+            const uint32_t p = s.loff[bin[i]] + rank[i];
+            s.stage[p] = rec[i];
+            s.sbin[p] = (uint16_t)bin[i];
+        }
+    __syncthreads();
+    const uint32_t total = s.total;
+    for (uint32_t j = tid; j < total; j += MS_THREADS) {
+        const uint32_t b = s.sbin[j];
+        out[s.gbase[b] + (j - s.loff[b])] = s.stage[j];
+    }
+    __syncthreads();
+}
+
+// histogram flavour of the same round (no data movement): adds this tile's bin counts to an LDS
+// histogram that the caller flushes once per workgroup
+__device__ __forceinline__ void block_hist_add(uint32_t* s_hist, const uint32_t (&bin)[MS_ITEMS]) {
+#pragma unroll
+    for (int i = 0; i < MS_ITEMS; ++i) if (bin[i] != BIN_NONE) atomicAdd(&s_hist[bin[i]], 1u);
+}
+
+}  // namespace kq

@@ -12,6 +12,7 @@
 
 #include "../../include/kreeq_amd.h"
 #include "kq_device.h"
+#include "kq_partition.h"
 
 using namespace kq;
 
@@ -139,6 +140,178 @@ __global__ __launch_bounds__(TILE_THREADS) void k_part_scatter(const uint8_t* __
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+// partitioned count path (kq_partition.h)
+// ------------------------------------------------------------------------------------------------
+
+// P1 pass A: how many records each coarse bucket will receive
+__global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+                                                          PartCfg cfg, unsigned long long* __restrict__ coarse_count) {
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    __shared__ uint32_t s_hist[NB_MAX];
+    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += TILE_THREADS) s_hist[b] = 0;
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);         // barrier inside (also covers the zeroing above)
+        tile_lane_scan_all(s_codes, s_inv, k, [&](int, bool valid, uint64_t fw, uint32_t, uint32_t) {
+            if (valid) {
+                const uint64_t rv = revcomp2(fw, k);
+                atomicAdd(&s_hist[(uint32_t)(region_id(fw < rv ? fw : rv, cfg.n_regions) >> cfg.g_shift)], 1u);
+            }
+        });
+        __syncthreads();
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += TILE_THREADS)
+        if (s_hist[b]) atomicAdd(&coarse_count[b], (unsigned long long)s_hist[b]);
+}
+
+// P1 pass B: (key, edge) records into their coarse bucket
+__global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+                                                             PartCfg cfg, unsigned long long* __restrict__ coarse_cursor,
+                                                             uint64_t* __restrict__ recs) {
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    __shared__ MsShared s;
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        uint64_t rec[MS_ITEMS];
+        uint32_t bin[MS_ITEMS];
+        tile_lane_scan_all(s_codes, s_inv, k, [&](int i, bool valid, uint64_t fw, uint32_t prev, uint32_t next) {
+            const uint64_t rv = revcomp2(fw, k);
+            const bool is_fw = fw < rv;
+            const uint64_t key = is_fw ? fw : rv;
+            rec[i] = rec_pack(key, pack_to_edge_byte(edge_pack(is_fw, prev, next)));
+            bin[i] = valid ? (uint32_t)(region_id(key, cfg.n_regions) >> cfg.g_shift) : BIN_NONE;
+        });
+        block_multisplit(s, rec, bin, cfg.n_coarse, coarse_cursor, recs);   // ends with a barrier
+    }
+}
+
+// P2: records of one coarse bucket -> grouped by region.  A workgroup owns a contiguous span of
+// the coarse-sorted array; spans are cut at coarse-bucket boundaries ("segments").
+__device__ __forceinline__ uint32_t bucket_of_pos(const unsigned long long* coarse_off, uint32_t n_coarse, uint64_t pos) {
+    uint32_t lo = 0, hi = n_coarse;               // largest b with coarse_off[b] <= pos
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (coarse_off[mid] <= pos) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(MS_THREADS) void k_p2_hist(const uint64_t* __restrict__ recs, uint64_t n_cap, PartCfg cfg,
+                                                        const unsigned long long* __restrict__ coarse_off,
+                                                        unsigned long long* __restrict__ fine_count) {
+    __shared__ uint32_t s_hist[NB_MAX];
+    const uint32_t nb = 1u << cfg.g_shift;
+    const uint64_t n = coarse_off[cfg.n_coarse] < n_cap ? coarse_off[cfg.n_coarse] : n_cap;   // true record count
+    uint64_t span = (n + gridDim.x - 1) / gridDim.x;
+    span = (span + MS_TILE - 1) / MS_TILE * MS_TILE;
+    uint64_t pos = (uint64_t)blockIdx.x * span;
+    const uint64_t end = pos + span < n ? pos + span : n;
+    while (pos < end) {
+        const uint32_t b = bucket_of_pos(coarse_off, cfg.n_coarse, pos);
+        const uint64_t seg_end = coarse_off[b + 1] < end ? coarse_off[b + 1] : end;
+        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS) s_hist[i] = 0;
+        __syncthreads();
+        const uint64_t rbase = (uint64_t)b << cfg.g_shift;
+        for (uint64_t i = pos + threadIdx.x; i < seg_end; i += MS_THREADS)
+            atomicAdd(&s_hist[(uint32_t)(region_id(rec_key(recs[i]), cfg.n_regions) - rbase)], 1u);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS)
+            if (s_hist[i]) atomicAdd(&fine_count[rbase + i], (unsigned long long)s_hist[i]);
+        __syncthreads();
+        pos = seg_end;
+    }
+}
+__global__ __launch_bounds__(MS_THREADS) void k_p2_scatter(const uint64_t* __restrict__ recs, uint64_t n_cap, PartCfg cfg,
+                                                           const unsigned long long* __restrict__ coarse_off,
+                                                           unsigned long long* __restrict__ fine_cursor, uint64_t* __restrict__ out) {
+    __shared__ MsShared s;
+    const uint32_t nb = 1u << cfg.g_shift;
+    const uint64_t n = coarse_off[cfg.n_coarse] < n_cap ? coarse_off[cfg.n_coarse] : n_cap;   // true record count
+    uint64_t span = (n + gridDim.x - 1) / gridDim.x;
+    span = (span + MS_TILE - 1) / MS_TILE * MS_TILE;
+    uint64_t pos = (uint64_t)blockIdx.x * span;
+    const uint64_t end = pos + span < n ? pos + span : n;
+    while (pos < end) {
+        const uint32_t b = bucket_of_pos(coarse_off, cfg.n_coarse, pos);
+        const uint64_t seg_end = coarse_off[b + 1] < end ? coarse_off[b + 1] : end;
+        const uint64_t rbase = (uint64_t)b << cfg.g_shift;
+        for (; pos < seg_end; pos += MS_TILE) {
+            uint64_t rec[MS_ITEMS];
+            uint32_t bin[MS_ITEMS];
+#pragma unroll
+            for (int j = 0; j < MS_ITEMS; ++j) {
+                const uint64_t i = pos + (uint64_t)j * MS_THREADS + threadIdx.x;
+                const bool ok = i < seg_end;
+                rec[j] = ok ? recs[i] : 0;
+                bin[j] = ok ? (uint32_t)(region_id(rec_key(rec[j]), cfg.n_regions) - rbase) : BIN_NONE;
+            }
+            block_multisplit(s, rec, bin, nb, fine_cursor + rbase, out);
+        }
+        pos = seg_end;
+    }
+}
+
+// P3: one workgroup per table region.  The region's 4096 slots (96 KiB) are staged in LDS, all
+// records of the region are applied with LDS atomics (same two-tier rule as table_add), and the
+// image is streamed back.  Global atomics only for the rare high-copy tier and the two totals.
+constexpr int P3_THREADS = 512;
+__global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const uint64_t* __restrict__ recs,
+                                                              const unsigned long long* __restrict__ region_base) {
+    __shared__ uint64_t s_img[REGION_SLOTS * 3];
+    __shared__ unsigned long long s_new, s_kmers;
+    const int tid = threadIdx.x;
+    for (uint64_t r = blockIdx.x; r < t.n_regions; r += gridDim.x) {
+        const uint64_t lo = region_base[r], hi = region_base[r + 1];
+        if (lo == hi) continue;                                         // block-uniform
+        uint4* gimg = reinterpret_cast<uint4*>(t.slots + (r << REGION_SHIFT));
+        uint4* limg = reinterpret_cast<uint4*>(s_img);
+        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+        if (tid == 0) { s_new = 0; s_kmers = 0; }
+        __syncthreads();
+        uint32_t n_new = 0, n_ok = 0;
+        for (uint64_t i = lo + tid; i < hi; i += P3_THREADS) {
+            const uint64_t rec = recs[i];
+            const uint64_t key = rec_key(rec);
+            const uint64_t pack = edge_byte_to_pack(rec_edge(rec));
+            const uint32_t off = (uint32_t)mix64(key) & (REGION_SLOTS - 1);
+            uint64_t* slot = nullptr;
+            for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
+                uint64_t* s = s_img + 3 * ((off + probe) & (REGION_SLOTS - 1));
+                uint64_t cur = *(volatile uint64_t*)s;
+                if (cur == EMPTY_KEY) {
+                    cur = atomicCAS((unsigned long long*)s, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                    if (cur == EMPTY_KEY) { ++n_new; slot = s; break; }
+                }
+                if (cur == key) { slot = s; break; }
+            }
+            if (!slot) { atomicOr(&t.st->err_table_full, 1u); continue; }
+            ++n_ok;
+            const uint64_t old = atomicAdd((unsigned long long*)&slot[2], 1ull);
+            if (old + 1 <= LOW_TIER_MAX) {
+                if (pack) atomicAdd((unsigned long long*)&slot[1], (unsigned long long)pack);
+            } else if (pack) {
+                HcSlot* hs = hc_upsert(t, key);
+                if (!hs) { atomicOr(&t.st->err_hc_full, 1u); continue; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if ((pack >> (8 * e)) & 1) atomicAdd((unsigned long long*)&hs->cnt[e], 1ull);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { n_new += __shfl_down(n_new, o, 64); n_ok += __shfl_down(n_ok, o, 64); }
+        if ((tid & 63) == 0) { if (n_new) atomicAdd(&s_new, (unsigned long long)n_new); if (n_ok) atomicAdd(&s_kmers, (unsigned long long)n_ok); }
+        __syncthreads();
+        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) gimg[i] = limg[i];
+        if (tid == 0) {
+            if (s_new) atomicAdd(&t.st->slots_used, s_new);
+            if (s_kmers) atomicAdd(&t.st->kmers_added, s_kmers);
+        }
+        __syncthreads();
+    }
+}
+
 // K2 on explicit records: processBuffers :160-206
 __global__ __launch_bounds__(256) void k_insert_records(TableView t, const uint64_t* __restrict__ keys,
                                                          const uint8_t* __restrict__ edges, uint64_t n) {
@@ -221,9 +394,16 @@ __global__ __launch_bounds__(256) void k_rehash_hc(TableView dst, const HcSlot* 
         for (int e = 0; e < 8; ++e) d->cnt[e] = old[i].cnt[e];
     }
 }
-__global__ void k_fill_keys(uint64_t* p, uint64_t stride_words, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        p[i * stride_words] = EMPTY_KEY;
+// table initialisation in one streaming pass: word i of the table is EMPTY_KEY when it is the key
+// word of a slot (i % words_per_slot == 0) and 0 otherwise; 16 B per lane per store.
+__global__ __launch_bounds__(256) void k_clear_slots(ulonglong2* p, uint32_t words_per_slot, uint64_t n_pairs) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = 2 * i;
+        ulonglong2 v;
+        v.x = (w % words_per_slot == 0) ? EMPTY_KEY : 0ull;
+        v.y = ((w + 1) % words_per_slot == 0) ? EMPTY_KEY : 0ull;
+        p[i] = v;
+    }
 }
 
 // K5: summary (src/graph-builder.cpp:240-282).  hist_small[c] for cov < HIST_SMALL; rarer larger
@@ -370,6 +550,9 @@ struct kq_handle {
     void* stage = nullptr; size_t stage_bytes = 0;     // device staging for host-buffer entry points
     uint64_t kmers_bound = 0;        // upper bound of instances inserted (sizing the side table)
     uint64_t used_bound = 0;         // upper bound of occupied slots (skips the state read-back)
+    bool trust_capacity = false;     // KQ_OPT_TRUST_CAPACITY: capacity_hint bounds the distinct k-mers
+    int count_path = 0;              // KQ_OPT_COUNT_PATH: 0 auto, 1 direct (global atomics), 2 partitioned
+    void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
 
     TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; return v; }
     uint64_t n_slots() const { return n_regions << REGION_SHIFT; }
@@ -392,14 +575,15 @@ static int ensure_buf(void** p, size_t* have, size_t need) {
     return KQ_OK;
 }
 
+static void clear_words(kq_handle* h, void* p, uint32_t words_per_slot, uint64_t n_slots) {
+    const uint64_t n_pairs = n_slots * words_per_slot / 2;      // both table sizes make this exact
+    hipLaunchKernelGGL(k_clear_slots, dim3(grid_for(h, n_pairs, 256)), dim3(256), 0, h->stream, (ulonglong2*)p, words_per_slot, n_pairs);
+}
 static int alloc_main(kq_handle* h, uint64_t n_regions, Slot** out) {
     Slot* p = nullptr;
     size_t bytes = (size_t)(n_regions << REGION_SHIFT) * sizeof(Slot);
     HIPC(hipMalloc((void**)&p, bytes));
-    hipError_t e = hipMemsetAsync(p, 0, bytes, h->stream);
-    if (e != hipSuccess) { hipFree(p); return fail(KQ_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)); }
-    uint64_t n = n_regions << REGION_SHIFT;
-    hipLaunchKernelGGL(k_fill_keys, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, (uint64_t*)p, (uint64_t)3, n);
+    clear_words(h, p, 3, n_regions << REGION_SHIFT);
     *out = p;
     return KQ_OK;
 }
@@ -407,9 +591,7 @@ static int alloc_hc(kq_handle* h, uint64_t cap, HcSlot** out) {
     HcSlot* p = nullptr;
     size_t bytes = (size_t)cap * sizeof(HcSlot);
     HIPC(hipMalloc((void**)&p, bytes));
-    hipError_t e = hipMemsetAsync(p, 0, bytes, h->stream);
-    if (e != hipSuccess) { hipFree(p); return fail(KQ_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)); }
-    hipLaunchKernelGGL(k_fill_keys, dim3(grid_for(h, cap, 256)), dim3(256), 0, h->stream, (uint64_t*)p, (uint64_t)9, cap);
+    clear_words(h, p, 9, cap);
     *out = p;
     return KQ_OK;
 }
@@ -431,55 +613,63 @@ static int check_errors(kq_handle* h) {
 
 // grow (rehash) so that `extra` more distinct k-mers fit at load <= 0.85, and the side table can
 // take every k-mer that may reach cov >= 255 after `extra_instances` more instances.
+static int grow_main(kq_handle* h, uint64_t need_slots) {
+    uint64_t want = h->n_slots();
+    while (want < need_slots) want *= 2;
+    const uint64_t new_regions = want >> REGION_SHIFT;
+    Slot* fresh = nullptr;
+    int rc = alloc_main(h, new_regions, &fresh);
+    if (rc) return rc == KQ_ERR_NOMEM ? fail(KQ_ERR_TABLE_FULL, "cannot grow k-mer table to %llu slots: out of device memory",
+                                             (unsigned long long)want) : rc;
+    Slot* old = h->slots; const uint64_t n_old = h->n_slots();
+    h->slots = fresh; h->n_regions = new_regions;
+    hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old, n_old);
+    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipFree(old));
+    return KQ_OK;
+}
+static int grow_hc(kq_handle* h, uint64_t need) {
+    uint64_t want = h->hc_cap;
+    while (want < need) want *= 2;
+    HcSlot* fresh = nullptr;
+    int rc = alloc_hc(h, want, &fresh);
+    if (rc) return rc;
+    HcSlot* old = h->hc; const uint64_t n_old = h->hc_cap;
+    h->hc = fresh; h->hc_cap = want;
+    HIPC(hipMemsetAsync(&h->st->hc_used, 0, sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(k_rehash_hc, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old, n_old);
+    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipFree(old));
+    return KQ_OK;
+}
+
+// Make room for a batch that may add `extra` distinct k-mers and `extra_instances` instances.
+//  main table : load <= 0.85 even if every k-mer of the batch is new (unless the caller vouched for
+//               capacity_hint with KQ_OPT_TRUST_CAPACITY); host-side upper bounds avoid a device round trip.
+//  side table : #k-mers with cov >= 255 <= instances / 255; kept at load <= 0.5 up to 2^23 entries
+//               (1.2 GB); beyond that growth follows the observed fill.
 static int reserve(kq_handle* h, uint64_t extra, uint64_t extra_instances) {
-    // fast path without a device round trip: host-side upper bounds say everything fits
-    {
-        const uint64_t need = (uint64_t)((double)(h->used_bound + extra) / 0.85) + REGION_SLOTS;
-        const uint64_t inst = h->kmers_bound + extra_instances;
-        if (need <= h->n_slots() && inst / 255 + 1 <= (1ull << 23) && 2 * (inst / 255 + 1) <= h->hc_cap) {
-            h->used_bound += extra;
-            h->kmers_bound = inst;
-            return KQ_OK;
+    int rc;
+    bool state_read = false;
+    if (!h->trust_capacity) {
+        uint64_t need = (uint64_t)((double)(h->used_bound + extra) / 0.85) + REGION_SLOTS;
+        if (need > h->n_slots()) {
+            rc = read_state(h); if (rc) return rc;
+            state_read = true;
+            h->used_bound = h->st_host->slots_used;
+            need = (uint64_t)((double)(h->used_bound + extra) / 0.85) + REGION_SLOTS;
+            if (need > h->n_slots()) { rc = grow_main(h, need); if (rc) return rc; }
         }
     }
-    int rc = read_state(h);
-    if (rc) return rc;
-    const uint64_t used = h->st_host->slots_used;
-    h->used_bound = used + extra;
-    uint64_t need_slots = (uint64_t)((double)(used + extra) / 0.85) + REGION_SLOTS;
-    if (need_slots > h->n_slots()) {
-        uint64_t want = h->n_slots();
-        while (want < need_slots) want *= 2;
-        uint64_t new_regions = want >> REGION_SHIFT;
-        Slot* fresh = nullptr;
-        rc = alloc_main(h, new_regions, &fresh);
-        if (rc) return rc == KQ_ERR_NOMEM ? fail(KQ_ERR_TABLE_FULL, "cannot grow k-mer table to %llu slots: out of device memory",
-                                                 (unsigned long long)want) : rc;
-        Slot* old = h->slots; uint64_t n_old = h->n_slots();
-        h->slots = fresh; h->n_regions = new_regions;
-        hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old, n_old);
-        HIPC(hipStreamSynchronize(h->stream));
-        HIPC(hipFree(old));
-    }
-    // side table: #keys with cov >= 255 <= instances / 255; keep load <= 0.5, but never reserve
-    // more than 2^24 slots (1.2 GB) up front -- beyond that growth follows the observed fill.
+    h->used_bound += extra;
     h->kmers_bound += extra_instances;
-    uint64_t bound = h->kmers_bound / 255 + 1;
+    const uint64_t bound = h->kmers_bound / 255 + 1;
     uint64_t need_hc = 2 * std::min<uint64_t>(bound, 1ull << 23);
-    need_hc = std::max<uint64_t>(need_hc, 4 * h->st_host->hc_used);
-    if (need_hc > h->hc_cap) {
-        uint64_t want = h->hc_cap;
-        while (want < need_hc) want *= 2;
-        HcSlot* fresh = nullptr;
-        rc = alloc_hc(h, want, &fresh);
-        if (rc) return rc;
-        HcSlot* old = h->hc; uint64_t n_old = h->hc_cap;
-        h->hc = fresh; h->hc_cap = want;
-        HIPC(hipMemsetAsync(&h->st->hc_used, 0, sizeof(unsigned long long), h->stream));
-        hipLaunchKernelGGL(k_rehash_hc, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old, n_old);
-        HIPC(hipStreamSynchronize(h->stream));
-        HIPC(hipFree(old));
+    if (bound > (1ull << 23)) {
+        if (!state_read) { rc = read_state(h); if (rc) return rc; }
+        need_hc = std::max<uint64_t>(need_hc, 4 * h->st_host->hc_used);
     }
+    if (need_hc > h->hc_cap) { rc = grow_hc(h, need_hc); if (rc) return rc; }
     return KQ_OK;
 }
 
@@ -561,6 +751,7 @@ void kq_destroy(kq_handle* h) {
     if (h->st_host) hipHostFree(h->st_host);
     if (h->scratch) hipFree(h->scratch);
     if (h->stage) hipFree(h->stage);
+    if (h->part) hipFree(h->part);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -568,10 +759,8 @@ void kq_destroy(kq_handle* h) {
 int kq_clear(kq_handle* h) {
     if (!h) return fail(KQ_ERR_INVALID, "null handle");
     HIPC(hipSetDevice(h->device));
-    HIPC(hipMemsetAsync(h->slots, 0, (size_t)h->n_slots() * sizeof(Slot), h->stream));
-    hipLaunchKernelGGL(k_fill_keys, dim3(grid_for(h, h->n_slots(), 256)), dim3(256), 0, h->stream, (uint64_t*)h->slots, (uint64_t)3, h->n_slots());
-    HIPC(hipMemsetAsync(h->hc, 0, (size_t)h->hc_cap * sizeof(HcSlot), h->stream));
-    hipLaunchKernelGGL(k_fill_keys, dim3(grid_for(h, h->hc_cap, 256)), dim3(256), 0, h->stream, (uint64_t*)h->hc, (uint64_t)9, h->hc_cap);
+    clear_words(h, h->slots, 3, h->n_slots());
+    clear_words(h, h->hc, 9, h->hc_cap);
     HIPC(hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream));
     h->kmers_bound = 0;
     h->used_bound = 0;
@@ -583,6 +772,16 @@ int kq_set_stream(kq_handle* h, void* s) {
     HIPC(hipStreamSynchronize(h->stream));
     h->stream = s ? (hipStream_t)s : h->own_stream;
     return KQ_OK;
+}
+int kq_set_option(kq_handle* h, int option, int64_t value) {
+    if (!h) return fail(KQ_ERR_INVALID, "null handle");
+    switch (option) {
+        case KQ_OPT_TRUST_CAPACITY: h->trust_capacity = value != 0; return KQ_OK;
+        case KQ_OPT_COUNT_PATH:
+            if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_COUNT_PATH must be 0, 1 or 2");
+            h->count_path = (int)value; return KQ_OK;
+        default: return fail(KQ_ERR_INVALID, "unknown option %d", option);
+    }
 }
 void* kq_get_stream(kq_handle* h) { return h ? (void*)h->stream : nullptr; }
 int kq_sync(kq_handle* h) {
@@ -606,6 +805,53 @@ int kq_get_info(kq_handle* h, kq_info* out) {
 }
 
 // ---- count ---------------------------------------------------------------------------------
+// partitioned count of one batch: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
+static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len) {
+    PartCfg cfg;
+    cfg.n_regions = h->n_regions;
+    uint32_t g = 0;
+    while ((1ull << (2 * g)) < cfg.n_regions) ++g;            // 2^g ~ sqrt(R): balanced fan-outs
+    cfg.g_shift = cfg.n_regions <= (uint64_t)NB_MAX ? 0 : g;
+    cfg.n_coarse = (uint32_t)((cfg.n_regions + (1ull << cfg.g_shift) - 1) >> cfg.g_shift);
+    const bool two_level = cfg.g_shift != 0;
+    const uint64_t n_max = len;                                // >= number of k-mers
+    const uint64_t R = cfg.n_regions;
+    // layout: recs1[n_max] recs2[n_max] coarse_off[NB_MAX+2] coarse_cur[NB_MAX+2] region_base[R+2] fine_cur[R+2] total[2]
+    const size_t need = (size_t)(2 * n_max + 2 * (NB_MAX + 2) + 2 * (R + 2) + 2) * 8;
+    int rc = ensure_buf(&h->part, &h->part_bytes, need);
+    if (rc) return rc;
+    uint64_t* recs1 = (uint64_t*)h->part;
+    uint64_t* recs2 = recs1 + n_max;
+    unsigned long long* coarse_off = (unsigned long long*)(recs2 + n_max);
+    unsigned long long* coarse_cur = coarse_off + NB_MAX + 2;
+    unsigned long long* region_base = coarse_cur + NB_MAX + 2;
+    unsigned long long* fine_cur = region_base + R + 2;
+    unsigned long long* total = fine_cur + R + 2;
+    const int grid_t = grid_for(h, n_tiles_of(lead, len), 1);
+    const int grid_ms = h->n_cu * 2;                           // MsShared = 56 KiB -> 2 workgroups per CU
+    HIPC(hipMemsetAsync(coarse_off, 0, (size_t)(2 * (NB_MAX + 2) + 2 * (R + 2) + 2) * 8, h->stream));
+    hipLaunchKernelGGL(k_p1_hist, dim3(grid_t), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, coarse_off);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, coarse_off, (uint64_t)cfg.n_coarse + 1, total);
+    HIPC(hipMemcpyAsync(coarse_cur, coarse_off, (size_t)(cfg.n_coarse + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_p1_scatter, dim3(std::min(grid_t, grid_ms)), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, coarse_cur,
+                       recs1);
+    const uint64_t* sorted = recs1;
+    const unsigned long long* base = coarse_off;
+    if (two_level) {
+        // the number of records is only known on the device: the P2 kernels take n = len as an upper
+        // bound of their span and stop at coarse_off[n_coarse] (the true count)
+        hipLaunchKernelGGL(k_p2_hist, dim3(grid_ms), dim3(MS_THREADS), 0, h->stream, recs1, n_max, cfg, coarse_off, region_base);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, region_base, R + 1, total + 1);
+        HIPC(hipMemcpyAsync(fine_cur, region_base, (size_t)(R + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
+        hipLaunchKernelGGL(k_p2_scatter, dim3(grid_ms), dim3(MS_THREADS), 0, h->stream, recs1, n_max, cfg, coarse_off, fine_cur, recs2);
+        sorted = recs2;
+        base = region_base;
+    }
+    hipLaunchKernelGGL(k_count_regions, dim3(grid_for(h, R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted, base);
+    HIPC(hipGetLastError());
+    return KQ_OK;
+}
+
 int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
     if (!h || (!d_bases && len)) return fail(KQ_ERR_INVALID, "null argument");
     HIPC(hipSetDevice(h->device));
@@ -615,6 +861,13 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
     if (rc) return rc;
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
+    bool part = h->k <= PART_MAX_K && kmers >= (1u << 20) && h->n_regions <= (uint64_t)NB_MAX * NB_MAX;
+    if (h->count_path == 1) part = false;
+    if (h->count_path == 2) {
+        if (h->k > PART_MAX_K) return fail(KQ_ERR_INVALID, "partitioned count path needs k <= %d", PART_MAX_K);
+        part = true;
+    }
+    if (part) return count_partitioned(h, ab, lead, len);
     hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, len), 1)), dim3(TILE_THREADS), 0, h->stream,
                        h->view(), ab, lead, len, h->k);
     HIPC(hipGetLastError());

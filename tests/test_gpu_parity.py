@@ -296,3 +296,45 @@ def test_errors(kq):
     assert db.summary()["distinct"] == 0
     c, _ = db.lookup_sequence(b"ACGT")
     assert c.tolist() == [0, 0, 0]
+
+
+# ---------------------------------------------------------------------------------- partitioned count path
+@pytest.mark.parametrize("k,hint", [(21, 0), (21, 5_000_000), (28, 3_000_000), (9, 0), (2, 0)])
+def test_partitioned_count_vs_oracle(kq, O, k, hint):
+    """P1 -> (P2) -> P3 path forced on: single-level (<= 1024 regions) and two-level splits"""
+    batch, genome = H.synth_reads(30000, 150, 80000, seed=50 + k, err=0.01, n_rate=0.003)
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=hint), O.OracleDB(k, 128)
+    gpu.set_option("count_path", "partitioned")
+    third = batch.rfind(b"\n", 0, len(batch) // 3)
+    for part in (batch[:third], batch[third + 1:]):            # two batches: P3 must merge into existing regions
+        gpu.count_batch(part)
+        cpu.count_batch(part, threads=8)
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(gpu.export(), cpu.export())
+    info = gpu.info()
+    assert info["kmers_counted"] == cpu.summary()["total"] and info["slots_used"] == cpu.summary()["distinct"]
+    cg, _ = gpu.lookup_sequence(genome)
+    cc, _ = cpu.validate_sequence(genome, threads=8)
+    assert np.array_equal(cg, cc)
+
+
+def test_partitioned_high_copy_and_mixed_paths(kq, O):
+    """hot k-mers (one region gets most records), then more batches through the direct path"""
+    rng = np.random.default_rng(3)
+    reads = [b"A" * 700, b"T" * 900, b"ACGT" * 200, b"CA" * 300]
+    batch1 = b"\n".join(reads[i] for i in rng.integers(0, 4, 400))
+    batch2, _ = H.synth_reads(5000, 120, 30000, seed=8, err=0.02, n_rate=0.01)
+    gpu, cpu = kq.KreeqDB(21, 128, capacity_hint=6_000_000), O.OracleDB(21, 128)
+    for path, b in (("partitioned", batch1), ("direct", batch2), ("partitioned", batch2), ("partitioned", batch1), ("direct", batch1)):
+        gpu.set_option("count_path", path)
+        gpu.count_batch(b)
+        cpu.count_batch(b, threads=8)
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(gpu.export(), cpu.export())
+
+
+def test_partitioned_rejects_large_k(kq):
+    db = kq.KreeqDB(31, 128)
+    db.set_option("count_path", "partitioned")
+    with pytest.raises(kq.KqError):
+        db.count_batch(b"ACGT" * 100)
