@@ -1,7 +1,7 @@
 // kq_device.h -- device-side building blocks shared by all kernels (gfx950 only).
 //
 // HBM layout (see DESIGN.md "Data layout"):
-//   main table   : n_regions x REGION_SLOTS slots of 24 B  { u64 key; u64 edges8; u64 cov }
+//   main table   : n_regions x REGION_SLOTS (2048) slots of 24 B  { u64 key; u64 edges8; u64 cov }
 //                  key   = canonical 2-bit k-mer (EMPTY = ~0, never a canonical key)
 //                  edges8= 8 packed u8 counters, byte e = edge e of include/kreeq.h:6-18
 //                          (e 0..3 = fw[A,C,G,T], 4..7 = bw[A,C,G,T]); only the first 254
@@ -21,8 +21,8 @@ namespace kq {
 constexpr uint64_t EMPTY_KEY = ~0ull;
 constexpr uint32_t LARGEST = 4294967295u;      // include/kreeq.h:68
 constexpr uint32_t LOW_TIER_MAX = 254;         // src/graph-builder.cpp:166: the 255th instance overflows
-constexpr int REGION_SHIFT = 12;
-constexpr uint32_t REGION_SLOTS = 1u << REGION_SHIFT;   // 4096 slots x 24 B = 96 KiB (fits LDS)
+constexpr int REGION_SHIFT = 11;
+constexpr uint32_t REGION_SLOTS = 1u << REGION_SHIFT;   // 2048 slots x 24 B = 48 KiB: three region images per CU's LDS
 
 struct Slot { uint64_t key, edges8, cov; };
 struct HcSlot { uint64_t key; uint64_t cnt[8]; };
@@ -231,20 +231,31 @@ __device__ __forceinline__ void convert16(const uint4& v, bool all_in, int64_t g
     }
 }
 
-// loads + converts one tile's 4096-byte window into LDS (ends with a barrier)
-__device__ __forceinline__ void tile_load(const uint8_t* __restrict__ ab, int64_t lo_valid, int64_t hi_valid, uint64_t tile,
-                                          uint32_t* s_codes, uint32_t* s_inv) {
+// global half of a tile load: this lane's 16 bytes of the tile's 4096-byte window (zeros outside)
+__device__ __forceinline__ uint4 tile_fetch(const uint8_t* __restrict__ ab, int64_t lo_valid, int64_t hi_valid, uint64_t tile) {
+    const int64_t g = (int64_t)(tile * TILE_STARTS) - 16 + 16 * (int)threadIdx.x;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (g + 16 > lo_valid && g < hi_valid) v = *reinterpret_cast<const uint4*>(ab + g);
+    return v;
+}
+// LDS half: convert to the 2-bit code stream + invalid-base bit stream (ends with a barrier)
+__device__ __forceinline__ void tile_store(const uint4& v, int64_t lo_valid, int64_t hi_valid, uint64_t tile,
+                                           uint32_t* s_codes, uint32_t* s_inv) {
     const int tid = threadIdx.x;
     const int64_t g = (int64_t)(tile * TILE_STARTS) - 16 + 16 * tid;
     uint32_t codes = 0, inv = 0xFFFFu;
     if (g + 16 > lo_valid && g < hi_valid) {
-        uint4 v = *reinterpret_cast<const uint4*>(ab + g);
         bool all_in = (g >= lo_valid) && (g + 16 <= hi_valid);
         convert16(v, all_in, g, lo_valid, hi_valid, codes, inv);
     }
     s_codes[tid] = codes;
     s_inv[tid] = inv;
     __syncthreads();
+}
+// loads + converts one tile's 4096-byte window into LDS (ends with a barrier)
+__device__ __forceinline__ void tile_load(const uint8_t* __restrict__ ab, int64_t lo_valid, int64_t hi_valid, uint64_t tile,
+                                          uint32_t* s_codes, uint32_t* s_inv) {
+    tile_store(tile_fetch(ab, lo_valid, hi_valid, tile), lo_valid, hi_valid, tile, s_codes, s_inv);
 }
 
 // this lane's 16 consecutive starts of the loaded tile; f(pos, fw, prev, next) per valid k-mer

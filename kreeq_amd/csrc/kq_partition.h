@@ -9,7 +9,8 @@
 // atomics, staged bucket-contiguous in LDS and copied out as coalesced runs; the only global
 // atomics are one reservation per (tile, non-empty bucket).
 //
-// Record (k <= 28): key in bits 0..2k-1, reference edge byte (include/kreeq.h:6-18) in bits 56..63.
+// Record (k <= 28): key in bits 0..2k-1; bits 56..58 = index of the fw edge (0..3, 7 = none),
+// bits 59..61 = index of the bw edge (0..3, 7 = none): a k-mer instance has at most one of each.
 #pragma once
 #include "kq_device.h"
 
@@ -29,9 +30,19 @@ struct PartCfg {
     uint32_t n_coarse;    // ceil(R / 2^g_shift) <= NB_MAX ; fan-out of P2 = 2^g_shift <= NB_MAX
 };
 
-__device__ __forceinline__ uint64_t rec_pack(uint64_t key, uint32_t edge_byte) { return key | ((uint64_t)edge_byte << REC_EDGE_SHIFT); }
+// fw/bw edge indices as src/graph-builder.cpp:98-110 assigns them
+__device__ __forceinline__ uint64_t rec_pack(uint64_t key, bool is_fw, uint32_t prev, uint32_t next) {
+    uint32_t f, b;
+    if (is_fw) { f = next < 4 ? next : 7u; b = prev < 4 ? prev : 7u; }
+    else       { f = prev < 4 ? 3u - prev : 7u; b = next < 4 ? 3u - next : 7u; }
+    return key | ((uint64_t)(f | (b << 3)) << REC_EDGE_SHIFT);
+}
 __device__ __forceinline__ uint64_t rec_key(uint64_t rec) { return rec & ((1ull << REC_EDGE_SHIFT) - 1); }
-__device__ __forceinline__ uint32_t rec_edge(uint64_t rec) { return (uint32_t)(rec >> REC_EDGE_SHIFT); }
+// packed u8x8 increment (byte e = edge e) of a record
+__device__ __forceinline__ uint64_t rec_edge_pack(uint64_t rec) {
+    const uint32_t f = (uint32_t)(rec >> REC_EDGE_SHIFT) & 7u, b = (uint32_t)(rec >> (REC_EDGE_SHIFT + 3)) & 7u;
+    return (f < 4 ? 1ull << (8 * f) : 0ull) | (b < 4 ? 1ull << (8 * (4 + b)) : 0ull);
+}
 __device__ __forceinline__ uint64_t region_id(uint64_t key, uint64_t n_regions) { return __umul64hi(mix64(key), n_regions); }
 
 struct MsShared {
@@ -77,9 +88,14 @@ __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&r
     for (int i = 0; i < MS_ITEMS; ++i) rank[i] = (bin[i] != BIN_NONE) ? atomicAdd(&s.hist[bin[i]], 1u) : 0u;
     __syncthreads();
     ms_scan(s, nb);
-    for (uint32_t b = tid; b < nb; b += MS_THREADS) {
-        const uint32_t c = s.hist[b];
-        if (c) s.gbase[b] = atomicAdd(&cursors[b], (unsigned long long)c);
+    // reserve global space: issue the (returning) atomics now, consume them after the staging
+    // phase so that their latency overlaps the LDS traffic below.  nb <= NB_MAX = 4 * MS_THREADS.
+    unsigned long long res[NB_MAX / MS_THREADS];
+#pragma unroll
+    for (int q = 0; q < NB_MAX / MS_THREADS; ++q) {
+        const uint32_t b = tid + q * MS_THREADS;
+        const uint32_t c = (b < nb) ? s.hist[b] : 0;
+        res[q] = c ? atomicAdd(&cursors[b], (unsigned long long)c) : 0ull;
     }
 #pragma unroll
     for (int i = 0; i < MS_ITEMS; ++i)
@@ -88,6 +104,11 @@ __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&r
             s.stage[p] = rec[i];
             s.sbin[p] = (uint16_t)bin[i];
         }
+#pragma unroll
+    for (int q = 0; q < NB_MAX / MS_THREADS; ++q) {
+        const uint32_t b = tid + q * MS_THREADS;
+        if (b < nb) s.gbase[b] = res[q];
+    }
     __syncthreads();
     const uint32_t total = s.total;
     for (uint32_t j = tid; j < total; j += MS_THREADS) {

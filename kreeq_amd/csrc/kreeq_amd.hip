@@ -177,15 +177,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __re
     __shared__ MsShared s;
     const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
     const uint64_t n_tiles = n_tiles_of(lead, len);
+    uint4 nxt = tile_fetch(ab, lo_valid, hi_valid, blockIdx.x);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        tile_store(nxt, lo_valid, hi_valid, tile, s_codes, s_inv);
+        if (tile + gridDim.x < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + gridDim.x);   // in flight during the split
         uint64_t rec[MS_ITEMS];
         uint32_t bin[MS_ITEMS];
         tile_lane_scan_all(s_codes, s_inv, k, [&](int i, bool valid, uint64_t fw, uint32_t prev, uint32_t next) {
             const uint64_t rv = revcomp2(fw, k);
             const bool is_fw = fw < rv;
             const uint64_t key = is_fw ? fw : rv;
-            rec[i] = rec_pack(key, pack_to_edge_byte(edge_pack(is_fw, prev, next)));
+            rec[i] = rec_pack(key, is_fw, prev, next);
             bin[i] = valid ? (uint32_t)(region_id(key, cfg.n_regions) >> cfg.g_shift) : BIN_NONE;
         });
         block_multisplit(s, rec, bin, cfg.n_coarse, coarse_cursor, recs);   // ends with a barrier
@@ -238,15 +240,26 @@ __global__ __launch_bounds__(MS_THREADS) void k_p2_scatter(const uint64_t* __res
         const uint32_t b = bucket_of_pos(coarse_off, cfg.n_coarse, pos);
         const uint64_t seg_end = coarse_off[b + 1] < end ? coarse_off[b + 1] : end;
         const uint64_t rbase = (uint64_t)b << cfg.g_shift;
+        // software pipeline: the next round's records are loaded before this round is split
+        uint64_t nxt[MS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < MS_ITEMS; ++j) {
+            const uint64_t i = pos + (uint64_t)j * MS_THREADS + threadIdx.x;
+            nxt[j] = i < seg_end ? recs[i] : 0;
+        }
         for (; pos < seg_end; pos += MS_TILE) {
             uint64_t rec[MS_ITEMS];
             uint32_t bin[MS_ITEMS];
 #pragma unroll
             for (int j = 0; j < MS_ITEMS; ++j) {
                 const uint64_t i = pos + (uint64_t)j * MS_THREADS + threadIdx.x;
-                const bool ok = i < seg_end;
-                rec[j] = ok ? recs[i] : 0;
-                bin[j] = ok ? (uint32_t)(region_id(rec_key(rec[j]), cfg.n_regions) - rbase) : BIN_NONE;
+                rec[j] = nxt[j];
+                bin[j] = i < seg_end ? (uint32_t)(region_id(rec_key(rec[j]), cfg.n_regions) - rbase) : BIN_NONE;
+            }
+#pragma unroll
+            for (int j = 0; j < MS_ITEMS; ++j) {
+                const uint64_t i = pos + MS_TILE + (uint64_t)j * MS_THREADS + threadIdx.x;
+                nxt[j] = i < seg_end ? recs[i] : 0;
             }
             block_multisplit(s, rec, bin, nb, fine_cursor + rbase, out);
         }
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_p2_scatter(const uint64_t* __res
     }
 }
 
-// P3: one workgroup per table region.  The region's 4096 slots (96 KiB) are staged in LDS, all
+// P3: one workgroup per table region.  The region's slots (REGION_SLOTS x 24 B) are staged in LDS, all
 // records of the region are applied with LDS atomics (same two-tier rule as table_add), and the
 // image is streamed back.  Global atomics only for the rare high-copy tier and the two totals.
 constexpr int P3_THREADS = 512;
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const
         for (uint64_t i = lo + tid; i < hi; i += P3_THREADS) {
             const uint64_t rec = recs[i];
             const uint64_t key = rec_key(rec);
-            const uint64_t pack = edge_byte_to_pack(rec_edge(rec));
+            const uint64_t pack = rec_edge_pack(rec);
             const uint32_t off = (uint32_t)mix64(key) & (REGION_SLOTS - 1);
             uint64_t* slot = nullptr;
             for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
@@ -840,7 +853,7 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     if (two_level) {
         // the number of records is only known on the device: the P2 kernels take n = len as an upper
         // bound of their span and stop at coarse_off[n_coarse] (the true count)
-        hipLaunchKernelGGL(k_p2_hist, dim3(grid_ms), dim3(MS_THREADS), 0, h->stream, recs1, n_max, cfg, coarse_off, region_base);
+        hipLaunchKernelGGL(k_p2_hist, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, recs1, n_max, cfg, coarse_off, region_base);
         hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, region_base, R + 1, total + 1);
         HIPC(hipMemcpyAsync(fine_cur, region_base, (size_t)(R + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
         hipLaunchKernelGGL(k_p2_scatter, dim3(grid_ms), dim3(MS_THREADS), 0, h->stream, recs1, n_max, cfg, coarse_off, fine_cur, recs2);
