@@ -45,6 +45,17 @@ struct TableView {
     DevState* st;
 };
 
+// Table hash: one xorshift-multiply-xorshift round (3 integer multiplies instead of murmur's 6+;
+// the integer multiplier is quarter rate on CDNA and dominated the scan kernels).  Region = top 32
+// bits scaled to n_regions (< 2^32), in-region offset = low bits.  Uniformity on k-mer sets is
+// indistinguishable from murmur3's finaliser (region occupancy sd = Poisson).
+__device__ __forceinline__ uint64_t table_hash(uint64_t key) {
+    uint64_t x = key ^ (key >> 32);
+    x *= 0x9E3779B97F4A7C15ull;
+    return x ^ (x >> 29);
+}
+__device__ __forceinline__ uint64_t hash_region(uint64_t h, uint64_t n_regions) { return __umulhi((uint32_t)(h >> 32), (uint32_t)n_regions); }
+
 __device__ __forceinline__ uint64_t mix64(uint64_t h) {
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
     h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
@@ -93,12 +104,12 @@ __device__ __forceinline__ uint64_t ld_relaxed(const uint64_t* p) {
 
 // ---- main table ------------------------------------------------------------------------------
 __device__ __forceinline__ Slot* region_of(const TableView& t, uint64_t h) {
-    return t.slots + (__umul64hi(h, t.n_regions) << REGION_SHIFT);
+    return t.slots + (hash_region(h, t.n_regions) << REGION_SHIFT);
 }
 
 // find-or-insert; returns nullptr when the region is full. *inserted = 1 for a new key.
 __device__ __forceinline__ Slot* table_upsert(const TableView& t, uint64_t key, uint32_t* inserted) {
-    const uint64_t h = mix64(key);
+    const uint64_t h = table_hash(key);
     Slot* base = region_of(t, h);
     uint32_t off = (uint32_t)h & (REGION_SLOTS - 1);
     for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
@@ -114,7 +125,7 @@ __device__ __forceinline__ Slot* table_upsert(const TableView& t, uint64_t key, 
 }
 
 __device__ __forceinline__ const Slot* table_find(const TableView& t, uint64_t key) {
-    const uint64_t h = mix64(key);
+    const uint64_t h = table_hash(key);
     const Slot* base = region_of(t, h);
     uint32_t off = (uint32_t)h & (REGION_SLOTS - 1);
     for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
@@ -258,60 +269,58 @@ __device__ __forceinline__ void tile_load(const uint8_t* __restrict__ ab, int64_
     tile_store(tile_fetch(ab, lo_valid, hi_valid, tile), lo_valid, hi_valid, tile, s_codes, s_inv);
 }
 
-// this lane's 16 consecutive starts of the loaded tile; f(pos, fw, prev, next) per valid k-mer
-template <class F>
-__device__ __forceinline__ void tile_lane_scan(const uint32_t* s_codes, const uint32_t* s_inv, int64_t lo_valid, uint64_t tile,
+// This lane's 16 consecutive k-mer starts of the loaded tile.  The forward word and its reverse
+// complement are ROLLED from start to start (2 shifts + or each) instead of re-extracted:
+//   fw' = (fw >> 2) | b[i+k] << (2k-2)        rv' = ((rv << 2) | (3 - b[i+k])) & mask
+// ALL = false: f(i, true, pos, fw, rv, prev, next) only for starts whose k bases are all ACGT;
+// ALL = true : f(...) for every start with a `valid` flag and the compile-time index i (lets
+//              callers fill register arrays with static indexing).
+// prev/next = neighbouring base codes, or 4 when that neighbour is not a base of the same run.
+template <bool ALL, class F>
+__device__ __forceinline__ void lane_scan_core(const uint32_t* s_codes, const uint32_t* s_inv, int64_t lo_valid, uint64_t tile,
                                                int k, F&& f) {
     const int tid = threadIdx.x;
-    if (tid >= TILE_STARTS / 16) return;
-    const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
-    const uint64_t wmask = (1ull << k) - 1;
-    const uint32_t c0 = s_codes[tid], c1 = s_codes[tid + 1], c2 = s_codes[tid + 2], c3 = s_codes[tid + 3];
-    const uint32_t m0 = s_inv[tid];
-    const uint64_t ms = (uint64_t)s_inv[tid + 1] | ((uint64_t)s_inv[tid + 2] << 16) | ((uint64_t)s_inv[tid + 3] << 32);
-    const uint64_t lo = (uint64_t)c1 | ((uint64_t)c2 << 32);
-    const uint64_t hi = (uint64_t)c3;
-    uint32_t prev = (m0 >> 15) ? 4u : (c0 >> 30);
-    const int64_t p0 = (int64_t)(tile * TILE_STARTS) + 16 * tid - lo_valid;   // caller position of start 0
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint64_t fw = ((i == 0) ? lo : ((lo >> (2 * i)) | (hi << (64 - 2 * i)))) & kmask;
-        const bool valid = ((ms >> i) & wmask) == 0;
-        if (valid) {
-            const int np = i + k;                                            // 2..47
-            uint32_t next = (np < 32) ? (uint32_t)(lo >> (2 * np)) & 3u : (uint32_t)(hi >> (2 * (np - 32))) & 3u;
-            if ((ms >> np) & 1) next = 4u;
-            f((uint64_t)(p0 + i), fw, prev, next);
-        }
-        prev = ((ms >> i) & 1) ? 4u : ((uint32_t)(lo >> (2 * i)) & 3u);
-    }
-}
-
-// same walk, but f(i, valid, fw, prev, next) is called for EVERY one of the 16 starts with the
-// compile-time index i, so callers can fill register arrays with static indexing
-template <class F>
-__device__ __forceinline__ void tile_lane_scan_all(const uint32_t* s_codes, const uint32_t* s_inv, int k, F&& f) {
-    const int tid = threadIdx.x;
     const bool lane_has_work = tid < TILE_STARTS / 16;
+    if (!ALL && !lane_has_work) return;
     const int t = lane_has_work ? tid : 0;
     const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
     const uint64_t wmask = (1ull << k) - 1;
+    const int top = 2 * k - 2;
     const uint32_t c0 = s_codes[t], c1 = s_codes[t + 1], c2 = s_codes[t + 2], c3 = s_codes[t + 3];
     const uint32_t m0 = s_inv[t];
     const uint64_t ms = (uint64_t)s_inv[t + 1] | ((uint64_t)s_inv[t + 2] << 16) | ((uint64_t)s_inv[t + 3] << 32);
     const uint64_t lo = (uint64_t)c1 | ((uint64_t)c2 << 32);
     const uint64_t hi = (uint64_t)c3;
     uint32_t prev = (m0 >> 15) ? 4u : (c0 >> 30);
+    const int64_t p0 = (int64_t)(tile * TILE_STARTS) + 16 * t - lo_valid;       // caller position of start 0
+    uint64_t fw = lo & kmask;
+    uint64_t rv = revcomp2(fw, k);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const uint64_t fw = ((i == 0) ? lo : ((lo >> (2 * i)) | (hi << (64 - 2 * i)))) & kmask;
         const bool valid = lane_has_work && (((ms >> i) & wmask) == 0);
-        const int np = i + k;
-        uint32_t next = (np < 32) ? (uint32_t)(lo >> (2 * np)) & 3u : (uint32_t)(hi >> (2 * (np - 32))) & 3u;
-        if ((ms >> np) & 1) next = 4u;
-        f(i, valid, fw, prev, next);
-        prev = ((ms >> i) & 1) ? 4u : ((uint32_t)(lo >> (2 * i)) & 3u);
+        const int np = i + k;                                                    // 2..47
+        const uint32_t nraw = (np < 32) ? (uint32_t)(lo >> (2 * np)) & 3u : (uint32_t)(hi >> (2 * (np - 32))) & 3u;
+        const uint32_t next = ((ms >> np) & 1) ? 4u : nraw;
+        if (ALL) f(i, valid, (uint64_t)(p0 + i), fw, rv, prev, next);
+        else if (valid) f(i, true, (uint64_t)(p0 + i), fw, rv, prev, next);
+        prev = ((ms >> i) & 1) ? 4u : ((uint32_t)fw & 3u);
+        fw = (fw >> 2) | ((uint64_t)nraw << top);
+        rv = ((rv << 2) | (uint64_t)(3u - nraw)) & kmask;
     }
+}
+
+// f(pos, fw, rv, prev, next) per valid k-mer
+template <class F>
+__device__ __forceinline__ void tile_lane_scan(const uint32_t* s_codes, const uint32_t* s_inv, int64_t lo_valid, uint64_t tile,
+                                               int k, F&& f) {
+    lane_scan_core<false>(s_codes, s_inv, lo_valid, tile, k,
+                          [&](int, bool, uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) { f(pos, fw, rv, prev, next); });
+}
+// f(i, valid, fw, rv, prev, next) for all 16 starts
+template <class F>
+__device__ __forceinline__ void tile_lane_scan_all(const uint32_t* s_codes, const uint32_t* s_inv, int k, F&& f) {
+    lane_scan_core<true>(s_codes, s_inv, 0, 0, k,
+                         [&](int i, bool valid, uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) { f(i, valid, fw, rv, prev, next); });
 }
 
 // number of valid k-mer starts among this lane's 16

@@ -19,15 +19,14 @@ namespace kq {
 constexpr int MS_THREADS = 256;
 constexpr int MS_ITEMS = 16;
 constexpr int MS_TILE = MS_THREADS * MS_ITEMS;   // 4096 records per multisplit round
-constexpr int NB_MAX = 1024;                     // max fan-out of one split
-constexpr uint32_t BIN_NONE = 0xFFFFu;
+constexpr int NB_MAX = 2048;                     // bins of one split incl. the discard bin: fan-out <= NB_MAX - 1
 constexpr int REC_EDGE_SHIFT = 56;
 constexpr int PART_MAX_K = 28;
 
 struct PartCfg {
     uint64_t n_regions;   // R
     uint32_t g_shift;     // coarse bucket = region >> g_shift
-    uint32_t n_coarse;    // ceil(R / 2^g_shift) <= NB_MAX ; fan-out of P2 = 2^g_shift <= NB_MAX
+    uint32_t n_coarse;    // ceil(R / 2^g_shift) < NB_MAX ; fan-out of P2 = 2^g_shift < NB_MAX
 };
 
 // fw/bw edge indices as src/graph-builder.cpp:98-110 assigns them
@@ -43,24 +42,24 @@ __device__ __forceinline__ uint64_t rec_edge_pack(uint64_t rec) {
     const uint32_t f = (uint32_t)(rec >> REC_EDGE_SHIFT) & 7u, b = (uint32_t)(rec >> (REC_EDGE_SHIFT + 3)) & 7u;
     return (f < 4 ? 1ull << (8 * f) : 0ull) | (b < 4 ? 1ull << (8 * (4 + b)) : 0ull);
 }
-__device__ __forceinline__ uint64_t region_id(uint64_t key, uint64_t n_regions) { return __umul64hi(mix64(key), n_regions); }
+__device__ __forceinline__ uint64_t region_id(uint64_t key, uint64_t n_regions) { return hash_region(table_hash(key), n_regions); }
 
 struct MsShared {
     uint64_t stage[MS_TILE];                 // 32 KiB
     uint16_t sbin[MS_TILE];                  //  8 KiB
-    uint32_t hist[NB_MAX];                   //  4 KiB
-    uint32_t loff[NB_MAX];                   //  4 KiB
-    unsigned long long gbase[NB_MAX];        //  8 KiB
+    uint32_t hist[NB_MAX];                   //  8 KiB
+    uint32_t loff[NB_MAX];                   //  8 KiB
+    unsigned long long gbase[NB_MAX];        // 16 KiB      (72 KiB in all: two workgroups per CU)
     uint32_t wave_sum[MS_THREADS / 64];
-    uint32_t total;
 };
+constexpr int MS_BINS_PER_THREAD = NB_MAX / MS_THREADS;
 
-// exclusive scan of s.hist[0..nb) into s.loff, total into s.total.  nb <= NB_MAX = 4 * MS_THREADS.
+// exclusive scan of s.hist[0..nb) into s.loff.  nb <= NB_MAX.
 __device__ __forceinline__ void ms_scan(MsShared& s, uint32_t nb) {
     const int tid = threadIdx.x;
-    uint32_t v[4], sum = 0;
+    uint32_t v[MS_BINS_PER_THREAD], sum = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { uint32_t b = 4 * tid + j; v[j] = (b < nb) ? s.hist[b] : 0; sum += v[j]; }
+    for (int j = 0; j < MS_BINS_PER_THREAD; ++j) { uint32_t b = MS_BINS_PER_THREAD * tid + j; v[j] = (b < nb) ? s.hist[b] : 0; sum += v[j]; }
     uint32_t incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { uint32_t n = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += n; }
@@ -70,59 +69,51 @@ __device__ __forceinline__ void ms_scan(MsShared& s, uint32_t nb) {
     for (int w = 0; w < (tid >> 6); ++w) base += s.wave_sum[w];
     uint32_t run = base + incl - sum;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { uint32_t b = 4 * tid + j; if (b < nb) s.loff[b] = run; run += v[j]; }
-    if (tid == MS_THREADS - 1) s.total = run;
+    for (int j = 0; j < MS_BINS_PER_THREAD; ++j) { uint32_t b = MS_BINS_PER_THREAD * tid + j; if (b < nb) s.loff[b] = run; run += v[j]; }
     __syncthreads();
 }
 
-// One multisplit round: every thread brings up to 16 records with their bins (BIN_NONE = no record).
+// One multisplit round: every thread brings 16 records with bins in [0, nb]; bin == nb means
+// "no record" (discard bin), which keeps the whole round free of per-record branches.
 // Space in `out` is reserved per bin with one atomicAdd on cursors[bin]; records of a bin land
-// contiguously there.  All threads of the block must call it.
+// contiguously there.  All threads of the block must call it.  nb < NB_MAX.
 __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&rec)[MS_ITEMS], const uint32_t (&bin)[MS_ITEMS], uint32_t nb,
                                                  unsigned long long* __restrict__ cursors, uint64_t* __restrict__ out) {
     const int tid = threadIdx.x;
-    for (uint32_t b = tid; b < nb; b += MS_THREADS) s.hist[b] = 0;
+    for (uint32_t b = tid; b <= nb; b += MS_THREADS) s.hist[b] = 0;
     __syncthreads();
     uint32_t rank[MS_ITEMS];
 #pragma unroll
-    for (int i = 0; i < MS_ITEMS; ++i) rank[i] = (bin[i] != BIN_NONE) ? atomicAdd(&s.hist[bin[i]], 1u) : 0u;
+    for (int i = 0; i < MS_ITEMS; ++i) rank[i] = atomicAdd(&s.hist[bin[i]], 1u);
     __syncthreads();
-    ms_scan(s, nb);
+    ms_scan(s, nb + 1);
     // reserve global space: issue the (returning) atomics now, consume them after the staging
-    // phase so that their latency overlaps the LDS traffic below.  nb <= NB_MAX = 4 * MS_THREADS.
-    unsigned long long res[NB_MAX / MS_THREADS];
+    // phase so that their latency overlaps the LDS traffic below
+    unsigned long long res[MS_BINS_PER_THREAD];
 #pragma unroll
-    for (int q = 0; q < NB_MAX / MS_THREADS; ++q) {
+    for (int q = 0; q < MS_BINS_PER_THREAD; ++q) {
         const uint32_t b = tid + q * MS_THREADS;
         const uint32_t c = (b < nb) ? s.hist[b] : 0;
         res[q] = c ? atomicAdd(&cursors[b], (unsigned long long)c) : 0ull;
     }
 #pragma unroll
-    for (int i = 0; i < MS_ITEMS; ++i)
-        if (bin[i] != BIN_NONE) {
-            const uint32_t p = s.loff[bin[i]] + rank[i];
-            s.stage[p] = rec[i];
-            s.sbin[p] = (uint16_t)bin[i];
-        }
+    for (int i = 0; i < MS_ITEMS; ++i) {
+        const uint32_t p = s.loff[bin[i]] + rank[i];
+        s.stage[p] = rec[i];
+        s.sbin[p] = (uint16_t)bin[i];
+    }
 #pragma unroll
-    for (int q = 0; q < NB_MAX / MS_THREADS; ++q) {
+    for (int q = 0; q < MS_BINS_PER_THREAD; ++q) {
         const uint32_t b = tid + q * MS_THREADS;
         if (b < nb) s.gbase[b] = res[q];
     }
     __syncthreads();
-    const uint32_t total = s.total;
+    const uint32_t total = s.loff[nb];           // records in front of the discard bin
     for (uint32_t j = tid; j < total; j += MS_THREADS) {
         const uint32_t b = s.sbin[j];
         out[s.gbase[b] + (j - s.loff[b])] = s.stage[j];
     }
     __syncthreads();
-}
-
-// histogram flavour of the same round (no data movement): adds this tile's bin counts to an LDS
-// histogram that the caller flushes once per workgroup
-__device__ __forceinline__ void block_hist_add(uint32_t* s_hist, const uint32_t (&bin)[MS_ITEMS]) {
-#pragma unroll
-    for (int i = 0; i < MS_ITEMS; ++i) if (bin[i] != BIN_NONE) atomicAdd(&s_hist[bin[i]], 1u);
 }
 
 }  // namespace kq

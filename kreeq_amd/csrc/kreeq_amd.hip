@@ -26,8 +26,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_count_direct(TableView t, cons
                                                                 uint64_t lead, uint64_t len, int k) {
     uint32_t n_new = 0;
     uint64_t n_kmers = 0;
-    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint32_t prev, uint32_t next) {
-        const uint64_t rv = revcomp2(fw, k);
+    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
         const bool is_fw = fw < rv;
         const uint64_t key = is_fw ? fw : rv;
         uint32_t ins = 0;
@@ -97,8 +96,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_emit_write(const uint8_t* __re
         uint32_t wave_base = 0;
         for (int w = 0; w < (tid >> 6); ++w) wave_base += s_wave[w];
         uint64_t out = tile_offsets[tile] + wave_base + (incl - mine);
-        tile_lane_scan(s_codes, s_inv, lo_valid, tile, k, [&](uint64_t, uint64_t fw, uint32_t prev, uint32_t next) {
-            const uint64_t rv = revcomp2(fw, k);
+        tile_lane_scan(s_codes, s_inv, lo_valid, tile, k, [&](uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
             const bool is_fw = fw < rv;
             if (out < cap) {
                 keys[out] = is_fw ? fw : rv;
@@ -120,8 +118,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_part_hist(const uint8_t* __res
     extern __shared__ unsigned long long s_hist[];
     for (uint32_t i = threadIdx.x; i < n_parts; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
-    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint32_t, uint32_t) {
-        const uint64_t rv = revcomp2(fw, k);
+    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
         atomicAdd(&s_hist[owner_part(fw < rv ? fw : rv, map_count, n_parts)], 1ull);
     });
     __syncthreads();
@@ -131,8 +128,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_part_hist(const uint8_t* __res
 __global__ __launch_bounds__(TILE_THREADS) void k_part_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
                                                                 uint32_t map_count, uint32_t n_parts, unsigned long long* part_cursor,
                                                                 uint64_t* keys, uint8_t* edges, uint64_t cap) {
-    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint32_t prev, uint32_t next) {
-        const uint64_t rv = revcomp2(fw, k);
+    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
         const bool is_fw = fw < rv;
         const uint64_t key = is_fw ? fw : rv;
         uint64_t o = atomicAdd(&part_cursor[owner_part(key, map_count, n_parts)], 1ull);
@@ -155,9 +151,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
     const uint64_t n_tiles = n_tiles_of(lead, len);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);         // barrier inside (also covers the zeroing above)
-        tile_lane_scan_all(s_codes, s_inv, k, [&](int, bool valid, uint64_t fw, uint32_t, uint32_t) {
+        tile_lane_scan_all(s_codes, s_inv, k, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
             if (valid) {
-                const uint64_t rv = revcomp2(fw, k);
                 atomicAdd(&s_hist[(uint32_t)(region_id(fw < rv ? fw : rv, cfg.n_regions) >> cfg.g_shift)], 1u);
             }
         });
@@ -183,12 +178,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __re
         if (tile + gridDim.x < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + gridDim.x);   // in flight during the split
         uint64_t rec[MS_ITEMS];
         uint32_t bin[MS_ITEMS];
-        tile_lane_scan_all(s_codes, s_inv, k, [&](int i, bool valid, uint64_t fw, uint32_t prev, uint32_t next) {
-            const uint64_t rv = revcomp2(fw, k);
+        tile_lane_scan_all(s_codes, s_inv, k, [&](int i, bool valid, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
             const bool is_fw = fw < rv;
             const uint64_t key = is_fw ? fw : rv;
             rec[i] = rec_pack(key, is_fw, prev, next);
-            bin[i] = valid ? (uint32_t)(region_id(key, cfg.n_regions) >> cfg.g_shift) : BIN_NONE;
+            bin[i] = valid ? (uint32_t)(region_id(key, cfg.n_regions) >> cfg.g_shift) : cfg.n_coarse;
         });
         block_multisplit(s, rec, bin, cfg.n_coarse, coarse_cursor, recs);   // ends with a barrier
     }
@@ -254,7 +248,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_p2_scatter(const uint64_t* __res
             for (int j = 0; j < MS_ITEMS; ++j) {
                 const uint64_t i = pos + (uint64_t)j * MS_THREADS + threadIdx.x;
                 rec[j] = nxt[j];
-                bin[j] = i < seg_end ? (uint32_t)(region_id(rec_key(rec[j]), cfg.n_regions) - rbase) : BIN_NONE;
+                bin[j] = i < seg_end ? (uint32_t)(region_id(rec_key(rec[j]), cfg.n_regions) - rbase) : nb;
             }
 #pragma unroll
             for (int j = 0; j < MS_ITEMS; ++j) {
@@ -289,7 +283,7 @@ __global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const
             const uint64_t rec = recs[i];
             const uint64_t key = rec_key(rec);
             const uint64_t pack = rec_edge_pack(rec);
-            const uint32_t off = (uint32_t)mix64(key) & (REGION_SLOTS - 1);
+            const uint32_t off = (uint32_t)table_hash(key) & (REGION_SLOTS - 1);
             uint64_t* slot = nullptr;
             for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
                 uint64_t* s = s_img + 3 * ((off + probe) & (REGION_SLOTS - 1));
@@ -490,8 +484,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_lookup(TableView t, const uint
                                                           int k, uint32_t map_count, uint32_t map_lo, uint32_t map_hi,
                                                           uint32_t cov_cutoff, kq_dbgbase* per_base, unsigned long long* counters) {
     uint64_t missing = 0, total = 0, edge_missing = 0;
-    scan_tiles(ab, lead, len, k, [&](uint64_t pos, uint64_t fw, uint32_t prev, uint32_t next) {
-        const uint64_t rv = revcomp2(fw, k);
+    scan_tiles(ab, lead, len, k, [&](uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
         const bool is_fw = fw < rv;                                        // :145
         const uint64_t key = is_fw ? fw : rv;
         const uint32_t m = (uint32_t)(key % map_count);                    // :146
@@ -824,7 +817,7 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     cfg.n_regions = h->n_regions;
     uint32_t g = 0;
     while ((1ull << (2 * g)) < cfg.n_regions) ++g;            // 2^g ~ sqrt(R): balanced fan-outs
-    cfg.g_shift = cfg.n_regions <= (uint64_t)NB_MAX ? 0 : g;
+    cfg.g_shift = cfg.n_regions < (uint64_t)NB_MAX ? 0 : g;
     cfg.n_coarse = (uint32_t)((cfg.n_regions + (1ull << cfg.g_shift) - 1) >> cfg.g_shift);
     const bool two_level = cfg.g_shift != 0;
     const uint64_t n_max = len;                                // >= number of k-mers
@@ -874,7 +867,7 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
     if (rc) return rc;
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
-    bool part = h->k <= PART_MAX_K && kmers >= (1u << 20) && h->n_regions <= (uint64_t)NB_MAX * NB_MAX;
+    bool part = h->k <= PART_MAX_K && kmers >= (1u << 20) && h->n_regions <= (1ull << 20);   // both fan-outs < NB_MAX
     if (h->count_path == 1) part = false;
     if (h->count_path == 2) {
         if (h->k > PART_MAX_K) return fail(KQ_ERR_INVALID, "partitioned count path needs k <= %d", PART_MAX_K);
