@@ -6,8 +6,8 @@
 //   P3  k_count_regions            per region: 96 KiB slot image in LDS, ds_* atomics, stream back
 //
 // Both splits are workgroup-level multisplits: a tile of <= 4096 records is ranked with LDS
-// atomics, staged bucket-contiguous in LDS and copied out as coalesced runs; the only global
-// atomics are one reservation per (tile, non-empty bucket).
+// atomics, staged bucket-contiguous in LDS and copied out as coalesced runs at the workgroup's
+// private cursors (count matrix + exclusive scan from a counting pass): no global atomics.
 //
 // Record (k <= 28): key in bits 0..2k-1; bits 56..58 = index of the fw edge (0..3, 7 = none),
 // bits 59..61 = index of the bw edge (0..3, 7 = none): a k-mer instance has at most one of each.
@@ -75,10 +75,11 @@ __device__ __forceinline__ void ms_scan(MsShared& s, uint32_t nb) {
 
 // One multisplit round: every thread brings 16 records with bins in [0, nb]; bin == nb means
 // "no record" (discard bin), which keeps the whole round free of per-record branches.
-// Space in `out` is reserved per bin with one atomicAdd on cursors[bin]; records of a bin land
-// contiguously there.  All threads of the block must call it.  nb < NB_MAX.
+// s.gbase[b] is the workgroup's PRIVATE running output cursor of bin b (set by the caller before
+// the first round, advanced here), so a round needs no global atomic at all; records of a bin
+// land contiguously at the cursor.  All threads of the block must call it.  nb < NB_MAX.
 __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&rec)[MS_ITEMS], const uint32_t (&bin)[MS_ITEMS], uint32_t nb,
-                                                 unsigned long long* __restrict__ cursors, uint64_t* __restrict__ out) {
+                                                 uint64_t* __restrict__ out) {
     const int tid = threadIdx.x;
     for (uint32_t b = tid; b <= nb; b += MS_THREADS) s.hist[b] = 0;
     __syncthreads();
@@ -87,25 +88,11 @@ __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&r
     for (int i = 0; i < MS_ITEMS; ++i) rank[i] = atomicAdd(&s.hist[bin[i]], 1u);
     __syncthreads();
     ms_scan(s, nb + 1);
-    // reserve global space: issue the (returning) atomics now, consume them after the staging
-    // phase so that their latency overlaps the LDS traffic below
-    unsigned long long res[MS_BINS_PER_THREAD];
-#pragma unroll
-    for (int q = 0; q < MS_BINS_PER_THREAD; ++q) {
-        const uint32_t b = tid + q * MS_THREADS;
-        const uint32_t c = (b < nb) ? s.hist[b] : 0;
-        res[q] = c ? atomicAdd(&cursors[b], (unsigned long long)c) : 0ull;
-    }
 #pragma unroll
     for (int i = 0; i < MS_ITEMS; ++i) {
         const uint32_t p = s.loff[bin[i]] + rank[i];
         s.stage[p] = rec[i];
         s.sbin[p] = (uint16_t)bin[i];
-    }
-#pragma unroll
-    for (int q = 0; q < MS_BINS_PER_THREAD; ++q) {
-        const uint32_t b = tid + q * MS_THREADS;
-        if (b < nb) s.gbase[b] = res[q];
     }
     __syncthreads();
     const uint32_t total = s.loff[nb];           // records in front of the discard bin
@@ -114,6 +101,8 @@ __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&r
         out[s.gbase[b] + (j - s.loff[b])] = s.stage[j];
     }
     __syncthreads();
+    // advance the cursors; the same thread zeroes hist[b] at the start of the next round
+    for (uint32_t b = tid; b < nb; b += MS_THREADS) s.gbase[b] += s.hist[b];
 }
 
 }  // namespace kq

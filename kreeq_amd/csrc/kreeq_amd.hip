@@ -139,10 +139,20 @@ __global__ __launch_bounds__(TILE_THREADS) void k_part_scatter(const uint8_t* __
 // ------------------------------------------------------------------------------------------------
 // partitioned count path (kq_partition.h)
 // ------------------------------------------------------------------------------------------------
+// No per-record and no per-run global atomics: every workgroup gets PRIVATE output cursors from a
+// counting pass (count matrix -> exclusive scan), because reservation atomics on a few hundred
+// shared cursors serialise per address (~11 ns each) and were the limiter of the first version.
 
-// P1 pass A: how many records each coarse bucket will receive
+constexpr int P1_F = 4;                 // hist workgroups per scatter workgroup (hist is light on LDS)
+constexpr uint32_t P2_UNIT = 8 * MS_TILE;   // records per P2 work unit (never crosses a coarse bucket)
+
+// column of hist workgroup vb in the count matrix: the P1_F hist workgroups whose tiles one scatter
+// workgroup b owns (vb = b, b+G1, ...) are adjacent, so b's output range per bin is contiguous
+__device__ __forceinline__ uint32_t p1_col(uint32_t vb, uint32_t g1) { return (vb % g1) * P1_F + vb / g1; }
+
+// P1 pass A: per-workgroup counts of coarse buckets -> M1[bin][column] (u64, bin-major)
 __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
-                                                          PartCfg cfg, unsigned long long* __restrict__ coarse_count) {
+                                                          PartCfg cfg, uint32_t g1, unsigned long long* __restrict__ m1) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
     __shared__ uint32_t s_hist[NB_MAX];
@@ -152,29 +162,36 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);         // barrier inside (also covers the zeroing above)
         tile_lane_scan_all(s_codes, s_inv, k, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
-            if (valid) {
-                atomicAdd(&s_hist[(uint32_t)(region_id(fw < rv ? fw : rv, cfg.n_regions) >> cfg.g_shift)], 1u);
-            }
+            if (valid) atomicAdd(&s_hist[(uint32_t)(region_id(fw < rv ? fw : rv, cfg.n_regions) >> cfg.g_shift)], 1u);
         });
         __syncthreads();
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += TILE_THREADS)
-        if (s_hist[b]) atomicAdd(&coarse_count[b], (unsigned long long)s_hist[b]);
+    const uint64_t cols = (uint64_t)g1 * P1_F;
+    const uint32_t col = p1_col(blockIdx.x, g1);
+    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += TILE_THREADS) m1[(uint64_t)b * cols + col] = s_hist[b];
 }
-
-// P1 pass B: (key, edge) records into their coarse bucket
+// after the scan of M1: coarse_off[b] = first output position of bucket b; [n_coarse] = #records
+__global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const unsigned long long* __restrict__ total, PartCfg cfg,
+                             uint32_t g1, unsigned long long* __restrict__ coarse_off) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < cfg.n_coarse) coarse_off[b] = m1[(uint64_t)b * g1 * P1_F];
+    if (b == cfg.n_coarse) coarse_off[b] = *total;
+}
+// P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
 __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
-                                                             PartCfg cfg, unsigned long long* __restrict__ coarse_cursor,
+                                                             PartCfg cfg, const unsigned long long* __restrict__ m1,
                                                              uint64_t* __restrict__ recs) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
     __shared__ MsShared s;
     const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
     const uint64_t n_tiles = n_tiles_of(lead, len);
+    const uint64_t cols = (uint64_t)gridDim.x * P1_F;
+    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += MS_THREADS) s.gbase[b] = m1[(uint64_t)b * cols + (uint64_t)blockIdx.x * P1_F];
     uint4 nxt = tile_fetch(ab, lo_valid, hi_valid, blockIdx.x);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_store(nxt, lo_valid, hi_valid, tile, s_codes, s_inv);
+        tile_store(nxt, lo_valid, hi_valid, tile, s_codes, s_inv);        // barrier inside (covers the cursor init)
         if (tile + gridDim.x < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + gridDim.x);   // in flight during the split
         uint64_t rec[MS_ITEMS];
         uint32_t bin[MS_ITEMS];
@@ -184,89 +201,147 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __re
             rec[i] = rec_pack(key, is_fw, prev, next);
             bin[i] = valid ? (uint32_t)(region_id(key, cfg.n_regions) >> cfg.g_shift) : cfg.n_coarse;
         });
-        block_multisplit(s, rec, bin, cfg.n_coarse, coarse_cursor, recs);   // ends with a barrier
+        block_multisplit(s, rec, bin, cfg.n_coarse, recs);   // ends with a barrier
     }
 }
 
-// P2: records of one coarse bucket -> grouped by region.  A workgroup owns a contiguous span of
-// the coarse-sorted array; spans are cut at coarse-bucket boundaries ("segments").
-__device__ __forceinline__ uint32_t bucket_of_pos(const unsigned long long* coarse_off, uint32_t n_coarse, uint64_t pos) {
-    uint32_t lo = 0, hi = n_coarse;               // largest b with coarse_off[b] <= pos
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (coarse_off[mid] <= pos) lo = mid; else hi = mid; }
-    return lo;
-}
-__global__ __launch_bounds__(MS_THREADS) void k_p2_hist(const uint64_t* __restrict__ recs, uint64_t n_cap, PartCfg cfg,
-                                                        const unsigned long long* __restrict__ coarse_off,
-                                                        unsigned long long* __restrict__ fine_count) {
-    __shared__ uint32_t s_hist[NB_MAX];
-    const uint32_t nb = 1u << cfg.g_shift;
-    const uint64_t n = coarse_off[cfg.n_coarse] < n_cap ? coarse_off[cfg.n_coarse] : n_cap;   // true record count
-    uint64_t span = (n + gridDim.x - 1) / gridDim.x;
-    span = (span + MS_TILE - 1) / MS_TILE * MS_TILE;
-    uint64_t pos = (uint64_t)blockIdx.x * span;
-    const uint64_t end = pos + span < n ? pos + span : n;
-    while (pos < end) {
-        const uint32_t b = bucket_of_pos(coarse_off, cfg.n_coarse, pos);
-        const uint64_t seg_end = coarse_off[b + 1] < end ? coarse_off[b + 1] : end;
-        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS) s_hist[i] = 0;
-        __syncthreads();
-        const uint64_t rbase = (uint64_t)b << cfg.g_shift;
-        for (uint64_t i = pos + threadIdx.x; i < seg_end; i += MS_THREADS)
-            atomicAdd(&s_hist[(uint32_t)(region_id(rec_key(recs[i]), cfg.n_regions) - rbase)], 1u);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS)
-            if (s_hist[i]) atomicAdd(&fine_count[rbase + i], (unsigned long long)s_hist[i]);
-        __syncthreads();
-        pos = seg_end;
+// P2 work units: bucket b is cut into ceil(size_b / P2_UNIT) units; unit_base = exclusive prefix
+__global__ __launch_bounds__(1024) void k_p2_units(const unsigned long long* __restrict__ coarse_off, PartCfg cfg,
+                                                   unsigned long long* __restrict__ unit_base) {
+    __shared__ unsigned long long s_n[NB_MAX];
+    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += blockDim.x)
+        s_n[b] = (coarse_off[b + 1] - coarse_off[b] + P2_UNIT - 1) / P2_UNIT;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (uint32_t b = 0; b < cfg.n_coarse; ++b) { unit_base[b] = run; run += s_n[b]; }
+        unit_base[cfg.n_coarse] = run;
     }
 }
-__global__ __launch_bounds__(MS_THREADS) void k_p2_scatter(const uint64_t* __restrict__ recs, uint64_t n_cap, PartCfg cfg,
+__device__ __forceinline__ uint32_t bucket_of_unit(const unsigned long long* unit_base, uint32_t n_coarse, uint64_t u) {
+    uint32_t lo = 0, hi = n_coarse;               // largest b with unit_base[b] <= u (skips empty buckets)
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (unit_base[mid] <= u) lo = mid; else hi = mid; }
+    return lo;
+}
+// P2 pass A: per-unit counts of the bucket's regions -> M2[unit][bin] (u32)
+__global__ __launch_bounds__(MS_THREADS) void k_p2_hist(const uint64_t* __restrict__ recs, PartCfg cfg,
+                                                        const unsigned long long* __restrict__ coarse_off,
+                                                        const unsigned long long* __restrict__ unit_base, uint32_t* __restrict__ m2) {
+    __shared__ uint32_t s_hist[NB_MAX];
+    const uint32_t nb = 1u << cfg.g_shift;
+    const uint64_t n_units = unit_base[cfg.n_coarse];
+    for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint32_t b = bucket_of_unit(unit_base, cfg.n_coarse, u);
+        const uint64_t lo = coarse_off[b] + (u - unit_base[b]) * P2_UNIT;
+        const uint64_t hi = lo + P2_UNIT < coarse_off[b + 1] ? lo + P2_UNIT : coarse_off[b + 1];
+        const uint64_t rbase = (uint64_t)b << cfg.g_shift;
+        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS) s_hist[i] = 0;
+        __syncthreads();
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += MS_THREADS)
+            atomicAdd(&s_hist[(uint32_t)(region_id(rec_key(recs[i]), cfg.n_regions) - rbase)], 1u);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS) m2[u * nb + i] = s_hist[i];
+        __syncthreads();
+    }
+}
+// per region: exclusive prefix of its counts over the bucket's units (in place), region total out
+__global__ __launch_bounds__(256) void k_p2_offsets(uint32_t* __restrict__ m2, PartCfg cfg, const unsigned long long* __restrict__ unit_base,
+                                                    unsigned long long* __restrict__ fine_count) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= cfg.n_regions) return;
+    const uint32_t nb = 1u << cfg.g_shift;
+    const uint32_t b = (uint32_t)(r >> cfg.g_shift), bin = (uint32_t)(r & (nb - 1));
+    unsigned long long run = 0;
+    for (uint64_t u = unit_base[b]; u < unit_base[b + 1]; ++u) {
+        const uint32_t c = m2[u * nb + bin];
+        m2[u * nb + bin] = (uint32_t)run;            // a region holds < 2^32 records of one batch
+        run += c;
+    }
+    fine_count[r] = run;
+}
+// P2 pass B: records -> grouped by region, private cursors = region_base + unit prefix
+__global__ __launch_bounds__(MS_THREADS) void k_p2_scatter(const uint64_t* __restrict__ recs, PartCfg cfg,
                                                            const unsigned long long* __restrict__ coarse_off,
-                                                           unsigned long long* __restrict__ fine_cursor, uint64_t* __restrict__ out) {
+                                                           const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
+                                                           const unsigned long long* __restrict__ region_base, uint64_t* __restrict__ out) {
     __shared__ MsShared s;
     const uint32_t nb = 1u << cfg.g_shift;
-    const uint64_t n = coarse_off[cfg.n_coarse] < n_cap ? coarse_off[cfg.n_coarse] : n_cap;   // true record count
-    uint64_t span = (n + gridDim.x - 1) / gridDim.x;
-    span = (span + MS_TILE - 1) / MS_TILE * MS_TILE;
-    uint64_t pos = (uint64_t)blockIdx.x * span;
-    const uint64_t end = pos + span < n ? pos + span : n;
-    while (pos < end) {
-        const uint32_t b = bucket_of_pos(coarse_off, cfg.n_coarse, pos);
-        const uint64_t seg_end = coarse_off[b + 1] < end ? coarse_off[b + 1] : end;
+    const uint64_t n_units = unit_base[cfg.n_coarse];
+    for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint32_t b = bucket_of_unit(unit_base, cfg.n_coarse, u);
+        const uint64_t lo = coarse_off[b] + (u - unit_base[b]) * P2_UNIT;
+        const uint64_t hi = lo + P2_UNIT < coarse_off[b + 1] ? lo + P2_UNIT : coarse_off[b + 1];
         const uint64_t rbase = (uint64_t)b << cfg.g_shift;
+        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS)
+            s.gbase[i] = (rbase + i < cfg.n_regions) ? region_base[rbase + i] + m2[u * nb + i] : 0ull;
+        __syncthreads();
         // software pipeline: the next round's records are loaded before this round is split
         uint64_t nxt[MS_ITEMS];
 #pragma unroll
         for (int j = 0; j < MS_ITEMS; ++j) {
-            const uint64_t i = pos + (uint64_t)j * MS_THREADS + threadIdx.x;
-            nxt[j] = i < seg_end ? recs[i] : 0;
+            const uint64_t i = lo + (uint64_t)j * MS_THREADS + threadIdx.x;
+            nxt[j] = i < hi ? recs[i] : 0;
         }
-        for (; pos < seg_end; pos += MS_TILE) {
+        for (uint64_t pos = lo; pos < hi; pos += MS_TILE) {
             uint64_t rec[MS_ITEMS];
             uint32_t bin[MS_ITEMS];
 #pragma unroll
             for (int j = 0; j < MS_ITEMS; ++j) {
                 const uint64_t i = pos + (uint64_t)j * MS_THREADS + threadIdx.x;
                 rec[j] = nxt[j];
-                bin[j] = i < seg_end ? (uint32_t)(region_id(rec_key(rec[j]), cfg.n_regions) - rbase) : nb;
+                bin[j] = i < hi ? (uint32_t)(region_id(rec_key(rec[j]), cfg.n_regions) - rbase) : nb;
             }
 #pragma unroll
             for (int j = 0; j < MS_ITEMS; ++j) {
                 const uint64_t i = pos + MS_TILE + (uint64_t)j * MS_THREADS + threadIdx.x;
-                nxt[j] = i < seg_end ? recs[i] : 0;
+                nxt[j] = i < hi ? recs[i] : 0;
             }
-            block_multisplit(s, rec, bin, nb, fine_cursor + rbase, out);
+            block_multisplit(s, rec, bin, nb, out);
         }
-        pos = seg_end;
     }
 }
+
+// multi-block exclusive scan helpers (chunks of SCAN_CHUNK elements per workgroup)
+constexpr uint32_t SCAN_CHUNK = 16384;
+__global__ __launch_bounds__(1024) void k_scan_sums(const unsigned long long* __restrict__ a, uint64_t n, unsigned long long* __restrict__ sums) {
+    const uint64_t lo = (uint64_t)blockIdx.x * SCAN_CHUNK, hi = lo + SCAN_CHUNK < n ? lo + SCAN_CHUNK : n;
+    unsigned long long v = 0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 1024) v += a[i];
+    uint64_t t = block_sum(v);
+    if (threadIdx.x == 0) sums[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(unsigned long long* __restrict__ a, uint64_t n, const unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long s_part[1024];
+    const uint64_t lo = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * (SCAN_CHUNK / 1024);
+    unsigned long long v[SCAN_CHUNK / 1024], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_CHUNK / 1024; ++j) { v[j] = lo + j < n ? a[lo + j] : 0; sum += v[j]; }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x < 64) {                      // wave 0 scans the 1024 partials, 16 per lane
+        unsigned long long loc[16], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { loc[j] = s_part[threadIdx.x * 16 + j]; tot += loc[j]; }
+        unsigned long long incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { unsigned long long nn = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += nn; }
+        unsigned long long run = incl - tot;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s_part[threadIdx.x * 16 + j] = run; run += loc[j]; }
+    }
+    __syncthreads();
+    unsigned long long run = sums[blockIdx.x] + s_part[threadIdx.x];
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_CHUNK / 1024; ++j) { if (lo + j < n) a[lo + j] = run; run += v[j]; }
+}
+
 
 // P3: one workgroup per table region.  The region's slots (REGION_SLOTS x 24 B) are staged in LDS, all
 // records of the region are applied with LDS atomics (same two-tier rule as table_add), and the
 // image is streamed back.  Global atomics only for the rare high-copy tier and the two totals.
 constexpr int P3_THREADS = 512;
 __global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const uint64_t* __restrict__ recs,
-                                                              const unsigned long long* __restrict__ region_base) {
+                                                              const unsigned long long* __restrict__ region_base, int table_is_empty) {
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
     __shared__ unsigned long long s_new, s_kmers;
     const int tid = threadIdx.x;
@@ -275,7 +350,11 @@ __global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const
         if (lo == hi) continue;                                         // block-uniform
         uint4* gimg = reinterpret_cast<uint4*>(t.slots + (r << REGION_SHIFT));
         uint4* limg = reinterpret_cast<uint4*>(s_img);
-        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+        if (table_is_empty) {            // first batch after kq_create / kq_clear: the image is known, skip the 48 KiB read
+            for (int i = tid; i < (int)(REGION_SLOTS * 3); i += P3_THREADS) s_img[i] = (i % 3 == 0) ? EMPTY_KEY : 0ull;
+        } else {
+            for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+        }
         if (tid == 0) { s_new = 0; s_kmers = 0; }
         __syncthreads();
         uint32_t n_new = 0, n_ok = 0;
@@ -556,6 +635,7 @@ struct kq_handle {
     void* stage = nullptr; size_t stage_bytes = 0;     // device staging for host-buffer entry points
     uint64_t kmers_bound = 0;        // upper bound of instances inserted (sizing the side table)
     uint64_t used_bound = 0;         // upper bound of occupied slots (skips the state read-back)
+    bool table_empty = true;         // nothing inserted since kq_create / kq_clear
     bool trust_capacity = false;     // KQ_OPT_TRUST_CAPACITY: capacity_hint bounds the distinct k-mers
     int count_path = 0;              // KQ_OPT_COUNT_PATH: 0 auto, 1 direct (global atomics), 2 partitioned
     void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
@@ -732,7 +812,7 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
             rc = fail(KQ_ERR_NOMEM, "state allocation failed"); break;
         }
         hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream);
-        uint64_t slots = (uint64_t)((double)(capacity_hint ? capacity_hint : (1u << 20)) / 0.6);
+        uint64_t slots = (uint64_t)((double)(capacity_hint ? capacity_hint : (1u << 20)) / 0.7);   // load <= 0.7 at the hinted size
         uint64_t regions = (slots + REGION_SLOTS - 1) >> REGION_SHIFT;
         if (regions < 16) regions = 16;
         rc = alloc_main(h, regions, &h->slots); if (rc) break;
@@ -770,6 +850,7 @@ int kq_clear(kq_handle* h) {
     HIPC(hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream));
     h->kmers_bound = 0;
     h->used_bound = 0;
+    h->table_empty = true;
     return KQ_OK;
 }
 
@@ -811,6 +892,19 @@ int kq_get_info(kq_handle* h, kq_info* out) {
 }
 
 // ---- count ---------------------------------------------------------------------------------
+// exclusive scan of n u64 on the device (in place); *total (device) receives the sum
+static int scan_u64(kq_handle* h, unsigned long long* a, uint64_t n, unsigned long long* sums_scratch, unsigned long long* total) {
+    if (n <= SCAN_CHUNK) {
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, a, n, total);
+        return KQ_OK;
+    }
+    const uint64_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)chunks), dim3(1024), 0, h->stream, a, n, sums_scratch);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, sums_scratch, chunks, total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)chunks), dim3(1024), 0, h->stream, a, n, sums_scratch);
+    return KQ_OK;
+}
+
 // partitioned count of one batch: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
 static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len) {
     PartCfg cfg;
@@ -822,38 +916,48 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     const bool two_level = cfg.g_shift != 0;
     const uint64_t n_max = len;                                // >= number of k-mers
     const uint64_t R = cfg.n_regions;
-    // layout: recs1[n_max] recs2[n_max] coarse_off[NB_MAX+2] coarse_cur[NB_MAX+2] region_base[R+2] fine_cur[R+2] total[2]
-    const size_t need = (size_t)(2 * n_max + 2 * (NB_MAX + 2) + 2 * (R + 2) + 2) * 8;
-    int rc = ensure_buf(&h->part, &h->part_bytes, need);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    const uint32_t g1 = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * 2);   // P1 scatter workgroups (72 KiB LDS: 2 per CU)
+    const uint64_t m1_n = (uint64_t)cfg.n_coarse * g1 * P1_F;
+    const uint32_t nb2 = 1u << cfg.g_shift;
+    const uint64_t max_units = n_max / P2_UNIT + cfg.n_coarse + 2;
+    const uint64_t m2_n = two_level ? max_units * nb2 : 0;     // u32 entries
+    const uint64_t sums_n = std::max(m1_n, R + 2) / SCAN_CHUNK + 2;
+    // layout (u64 words): recs1[n_max] recs2[n_max] m1[m1_n] coarse_off[NB_MAX+2] unit_base[NB_MAX+2]
+    //                     region_base[R+2] sums[sums_n] total[2] m2[(m2_n+1)/2]
+    const size_t words = (size_t)(2 * n_max + m1_n + 2 * (NB_MAX + 2) + (R + 2) + sums_n + 2 + (m2_n + 1) / 2);
+    int rc = ensure_buf(&h->part, &h->part_bytes, words * 8);
     if (rc) return rc;
     uint64_t* recs1 = (uint64_t*)h->part;
     uint64_t* recs2 = recs1 + n_max;
-    unsigned long long* coarse_off = (unsigned long long*)(recs2 + n_max);
-    unsigned long long* coarse_cur = coarse_off + NB_MAX + 2;
-    unsigned long long* region_base = coarse_cur + NB_MAX + 2;
-    unsigned long long* fine_cur = region_base + R + 2;
-    unsigned long long* total = fine_cur + R + 2;
-    const int grid_t = grid_for(h, n_tiles_of(lead, len), 1);
-    const int grid_ms = h->n_cu * 2;                           // MsShared = 56 KiB -> 2 workgroups per CU
-    HIPC(hipMemsetAsync(coarse_off, 0, (size_t)(2 * (NB_MAX + 2) + 2 * (R + 2) + 2) * 8, h->stream));
-    hipLaunchKernelGGL(k_p1_hist, dim3(grid_t), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, coarse_off);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, coarse_off, (uint64_t)cfg.n_coarse + 1, total);
-    HIPC(hipMemcpyAsync(coarse_cur, coarse_off, (size_t)(cfg.n_coarse + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
-    hipLaunchKernelGGL(k_p1_scatter, dim3(std::min(grid_t, grid_ms)), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, coarse_cur,
-                       recs1);
+    unsigned long long* m1 = (unsigned long long*)(recs2 + n_max);
+    unsigned long long* coarse_off = m1 + m1_n;
+    unsigned long long* unit_base = coarse_off + NB_MAX + 2;
+    unsigned long long* region_base = unit_base + NB_MAX + 2;
+    unsigned long long* sums = region_base + R + 2;
+    unsigned long long* total = sums + sums_n;
+    uint32_t* m2 = (uint32_t*)(total + 2);
+    // P1
+    hipLaunchKernelGGL(k_p1_hist, dim3(g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, g1, m1);
+    rc = scan_u64(h, m1, m1_n, sums, total);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, m1, total, cfg, g1, coarse_off);
+    hipLaunchKernelGGL(k_p1_scatter, dim3(g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, m1, recs1);
     const uint64_t* sorted = recs1;
     const unsigned long long* base = coarse_off;
     if (two_level) {
-        // the number of records is only known on the device: the P2 kernels take n = len as an upper
-        // bound of their span and stop at coarse_off[n_coarse] (the true count)
-        hipLaunchKernelGGL(k_p2_hist, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, recs1, n_max, cfg, coarse_off, region_base);
-        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, region_base, R + 1, total + 1);
-        HIPC(hipMemcpyAsync(fine_cur, region_base, (size_t)(R + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
-        hipLaunchKernelGGL(k_p2_scatter, dim3(grid_ms), dim3(MS_THREADS), 0, h->stream, recs1, n_max, cfg, coarse_off, fine_cur, recs2);
+        const int grid_ms = h->n_cu * 2;
+        hipLaunchKernelGGL(k_p2_units, dim3(1), dim3(1024), 0, h->stream, coarse_off, cfg, unit_base);
+        hipLaunchKernelGGL(k_p2_hist, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, recs1, cfg, coarse_off, unit_base, m2);
+        hipLaunchKernelGGL(k_p2_offsets, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, h->stream, m2, cfg, unit_base, region_base);
+        HIPC(hipMemsetAsync(region_base + R, 0, 8, h->stream));
+        rc = scan_u64(h, region_base, R + 1, sums, total + 1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_p2_scatter, dim3(grid_ms), dim3(MS_THREADS), 0, h->stream, recs1, cfg, coarse_off, unit_base, m2, region_base, recs2);
         sorted = recs2;
         base = region_base;
     }
-    hipLaunchKernelGGL(k_count_regions, dim3(grid_for(h, R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted, base);
+    hipLaunchKernelGGL(k_count_regions, dim3(grid_for(h, R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted, base, h->table_empty ? 1 : 0);
     HIPC(hipGetLastError());
     return KQ_OK;
 }
@@ -873,7 +977,12 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
         if (h->k > PART_MAX_K) return fail(KQ_ERR_INVALID, "partitioned count path needs k <= %d", PART_MAX_K);
         part = true;
     }
-    if (part) return count_partitioned(h, ab, lead, len);
+    if (part) {
+        rc = count_partitioned(h, ab, lead, len);
+        h->table_empty = false;
+        return rc;
+    }
+    h->table_empty = false;
     hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, len), 1)), dim3(TILE_THREADS), 0, h->stream,
                        h->view(), ab, lead, len, h->k);
     HIPC(hipGetLastError());
@@ -977,6 +1086,7 @@ int kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d
     if (!n) return KQ_OK;
     int rc = reserve(h, n, n);
     if (rc) return rc;
+    h->table_empty = false;
     hipLaunchKernelGGL(k_insert_records, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, h->view(), d_keys, d_edges, n);
     HIPC(hipGetLastError());
     return KQ_OK;
@@ -1117,6 +1227,7 @@ int kq_merge(kq_handle* dst, kq_handle* src) {
     if (rc) return rc;
     rc = reserve(dst, src->st_host->slots_used, src->st_host->kmers_added);
     if (rc) return rc;
+    dst->table_empty = false;
     hipLaunchKernelGGL(k_merge, dim3(grid_for(dst, src->n_slots(), 256)), dim3(256), 0, dst->stream, dst->view(), src->view());
     HIPC(hipGetLastError());
     return kq_sync(dst);
@@ -1137,6 +1248,7 @@ int kq_import(kq_handle* h, const kq_entry* entries, uint64_t n) {
     }
     int rc = reserve(h, n, inst);
     if (rc) return rc;
+    h->table_empty = false;
     void* d = nullptr;
     rc = stage_in(h, entries, n * sizeof(kq_entry), &d);
     if (rc) return rc;
