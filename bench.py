@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--capacity", type=int, default=24_000_000,
                     help="expected distinct k-mers per GPU (table = capacity/0.6 slots; the workload has 17.7 M)")
     ap.add_argument("--path", choices=["auto", "direct", "partitioned"], default="auto")
+    ap.add_argument("--sharded", action="store_true", help="with one GPU: still run the N>1 code path (owner split -> insert)")
     args = ap.parse_args()
 
     import torch
@@ -76,7 +77,7 @@ def main():
     engine = GpuEngine(K, 128, local_rank, capacity_hint=args.capacity)
     engine.db.set_option("trust_capacity", 1)     # the hint is an upper bound of the distinct k-mers (jellyfish -s style)
     engine.db.set_option("count_path", args.path)
-    counter = ShardedCounter(engine, K, 128)
+    counter = ShardedCounter(engine, K, 128, sharded_path=args.sharded)
 
     def step():
         engine.clear()
@@ -130,7 +131,7 @@ def main():
             "total_kmers_per_step": kmers_per_rank * world, "distinct_kmers": summ["distinct"],
             "distinct_kmers_per_s": summ["distinct"] * args.steps / dt,
             "roofline": {"bound": "hbm", "kernel": ("count_batch: k_p1_hist+k_p1_scatter+k_p2_hist+k_p2_scatter+k_count_regions" if args.path != "direct"
-                                                    else "k_count_direct") if world == 1 else "k_part_scatter+all_to_all+k_insert_records",
+                                                    else "k_count_direct") if world == 1 and not args.sharded else "owner split (k_p1_*) + all_to_all + k_lv_* + k_count_regions",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": kern_ms},
         }

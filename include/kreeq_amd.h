@@ -127,12 +127,20 @@ int  kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len);
 int  kq_emit_records(kq_handle* h, const char* bases, uint64_t len,
                      uint64_t* keys, uint8_t* edges, uint64_t cap, uint64_t* n_out);
 /* Device variant used to stage the multi-GPU exchange: records are grouped by owner part
- * (part p owns maps [p*map_count/n_parts, (p+1)*map_count/n_parts) of key % map_count; order
+ * (part p owns the maps m with floor(m * n_parts / map_count) == p, m = key % map_count; order
  * inside a part is unspecified).  d_keys/d_edges need room for len records; part_counts[n_parts]
  * is a HOST array. Synchronises. */
 int  kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts,
                              uint64_t* d_keys, uint8_t* d_edges, uint64_t cap,
                              uint64_t* part_counts);
+
+/* Same staging with PACKED 8-byte records (k <= 28): bits 0..2k-1 = key, bits 56..58 / 59..61 = index
+ * of the fw / bw edge the instance contributes (0..3, 7 = none; src/graph-builder.cpp:98-110).  One
+ * array to exchange instead of two, and the receive side (kq_insert_packed_dev) runs the
+ * partitioned, atomic-free count.  d_recs needs room for len - k + 1 records.  Synchronises. */
+int  kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts,
+                        uint64_t* d_recs, uint64_t cap, uint64_t* part_counts);
+int  kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n);
 
 /* Hot loop 2 only (DBG::processBuffers :160-206) on explicit records. */
 int  kq_insert_records(kq_handle* h, const uint64_t* keys, const uint8_t* edges, uint64_t n);

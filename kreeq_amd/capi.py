@@ -14,7 +14,7 @@ DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw",
 # every symbol include/kreeq_amd.h declares
 SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_get_info", "kq_last_error",
            "kq_abi_version", "kq_device_available", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
-           "kq_emit_partitioned_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
+           "kq_emit_partitioned_dev", "kq_emit_packed_dev", "kq_insert_packed_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
            "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_merge", "kq_import", "kq_export"]
 
 
@@ -90,6 +90,8 @@ def load():
     L.kq_count_batch_dev.argtypes = [vp, vp, u64]
     L.kq_emit_records.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
     L.kq_emit_partitioned_dev.argtypes = [vp, vp, u64, ci, vp, vp, u64, vp]
+    L.kq_emit_packed_dev.argtypes = [vp, vp, u64, ci, vp, u64, vp]
+    L.kq_insert_packed_dev.argtypes = [vp, vp, u64]
     L.kq_insert_records.argtypes = [vp, vp, vp, u64]
     L.kq_insert_records_dev.argtypes = [vp, vp, vp, u64]
     L.kq_summary.argtypes = [vp, C.POINTER(Stats)]
@@ -180,6 +182,14 @@ class KreeqDB:
         _check(load().kq_emit_partitioned_dev(self._h, C.c_void_p(bases_ptr), n, n_parts, C.c_void_p(keys_ptr), C.c_void_p(edges_ptr),
                                               cap, _p(counts)))
         return counts
+
+    def emit_packed_dev(self, bases_ptr, n, n_parts, recs_ptr, cap):
+        counts = np.zeros(n_parts, dtype=np.uint64)
+        _check(load().kq_emit_packed_dev(self._h, C.c_void_p(bases_ptr), n, n_parts, C.c_void_p(recs_ptr), cap, _p(counts)))
+        return counts
+
+    def insert_packed_dev(self, recs_ptr, n):
+        _check(load().kq_insert_packed_dev(self._h, C.c_void_p(recs_ptr), n))
 
     def insert_records(self, keys, edges):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

@@ -26,8 +26,24 @@ constexpr int PART_MAX_K = 28;
 struct PartCfg {
     uint64_t n_regions;   // R
     uint32_t g_shift;     // coarse bucket = region >> g_shift
-    uint32_t n_coarse;    // ceil(R / 2^g_shift) < NB_MAX ; fan-out of P2 = 2^g_shift < NB_MAX
+    uint32_t n_coarse;    // bins of P1: ceil(R / 2^g_shift) < NB_MAX (mode 0) or n_parts (mode 1)
+    uint32_t mode;        // 0: bin = coarse bucket of the key's table region; 1: bin = owner part (multi-GPU staging)
+    uint32_t map_count;   // mode 1: gfalibs mapCount
+    uint32_t map_mask;    // mode 1: map_count - 1 when it is a power of two, else 0
 };
+
+// One level of the record split.  Input records are grouped in n_seg segments (seg_off[0..n_seg]);
+// a record of segment b with table region r goes to bin (r >> out_shift) - (b << (seg_shift - out_shift)).
+//   flat -> coarse buckets : n_seg = 1, seg_shift = 32 (b == 0), out_shift = g_shift, nb = n_coarse
+//   coarse -> regions      : n_seg = n_coarse, seg_shift = g_shift, out_shift = 0, nb = 2^g_shift
+// Output group index = b * nb + bin (== the region id at the last level).
+struct LevelCfg {
+    uint64_t n_regions;
+    uint32_t n_seg, nb, seg_shift, out_shift;
+};
+__device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, uint64_t region) {
+    return (uint32_t)(region >> lv.out_shift) - (lv.seg_shift >= 32 ? 0u : (b << (lv.seg_shift - lv.out_shift)));
+}
 
 // fw/bw edge indices as src/graph-builder.cpp:98-110 assigns them
 __device__ __forceinline__ uint64_t rec_pack(uint64_t key, bool is_fw, uint32_t prev, uint32_t next) {
@@ -103,6 +119,16 @@ __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&r
     __syncthreads();
     // advance the cursors; the same thread zeroes hist[b] at the start of the next round
     for (uint32_t b = tid; b < nb; b += MS_THREADS) s.gbase[b] += s.hist[b];
+}
+
+// owner part of a key in the multi-GPU exchange: floor((key % map_count) * n_parts / map_count)
+__device__ __forceinline__ uint32_t owner_part_of(uint64_t key, uint32_t map_count, uint32_t map_mask, uint32_t n_parts) {
+    const uint32_t m = map_mask ? (uint32_t)key & map_mask : (uint32_t)(key % map_count);     // src/graph-builder.cpp:95
+    return (uint32_t)(((uint64_t)m * n_parts) / map_count);
+}
+__device__ __forceinline__ uint32_t p1_bin(const PartCfg& cfg, uint64_t key) {
+    return cfg.mode == 0 ? (uint32_t)(region_id(key, cfg.n_regions) >> cfg.g_shift)
+                         : owner_part_of(key, cfg.map_count, cfg.map_mask, cfg.n_coarse);
 }
 
 }  // namespace kq

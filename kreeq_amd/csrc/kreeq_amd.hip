@@ -162,7 +162,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);         // barrier inside (also covers the zeroing above)
         tile_lane_scan_all(s_codes, s_inv, k, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
-            if (valid) atomicAdd(&s_hist[(uint32_t)(region_id(fw < rv ? fw : rv, cfg.n_regions) >> cfg.g_shift)], 1u);
+            if (valid) atomicAdd(&s_hist[p1_bin(cfg, fw < rv ? fw : rv)], 1u);
         });
         __syncthreads();
     }
@@ -199,81 +199,78 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __re
             const bool is_fw = fw < rv;
             const uint64_t key = is_fw ? fw : rv;
             rec[i] = rec_pack(key, is_fw, prev, next);
-            bin[i] = valid ? (uint32_t)(region_id(key, cfg.n_regions) >> cfg.g_shift) : cfg.n_coarse;
+            bin[i] = valid ? p1_bin(cfg, key) : cfg.n_coarse;
         });
         block_multisplit(s, rec, bin, cfg.n_coarse, recs);   // ends with a barrier
     }
 }
 
-// P2 work units: bucket b is cut into ceil(size_b / P2_UNIT) units; unit_base = exclusive prefix
-__global__ __launch_bounds__(1024) void k_p2_units(const unsigned long long* __restrict__ coarse_off, PartCfg cfg,
+// ---- one generic level of the record split (LevelCfg) -----------------------------------------
+// work units: segment b is cut into ceil(size_b / P2_UNIT) units; unit_base = exclusive prefix
+__global__ __launch_bounds__(1024) void k_lv_units(const unsigned long long* __restrict__ seg_off, LevelCfg lv,
                                                    unsigned long long* __restrict__ unit_base) {
     __shared__ unsigned long long s_n[NB_MAX];
-    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += blockDim.x)
-        s_n[b] = (coarse_off[b + 1] - coarse_off[b] + P2_UNIT - 1) / P2_UNIT;
+    for (uint32_t b = threadIdx.x; b < lv.n_seg; b += blockDim.x)
+        s_n[b] = (seg_off[b + 1] - seg_off[b] + P2_UNIT - 1) / P2_UNIT;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long run = 0;
-        for (uint32_t b = 0; b < cfg.n_coarse; ++b) { unit_base[b] = run; run += s_n[b]; }
-        unit_base[cfg.n_coarse] = run;
+        for (uint32_t b = 0; b < lv.n_seg; ++b) { unit_base[b] = run; run += s_n[b]; }
+        unit_base[lv.n_seg] = run;
     }
 }
-__device__ __forceinline__ uint32_t bucket_of_unit(const unsigned long long* unit_base, uint32_t n_coarse, uint64_t u) {
-    uint32_t lo = 0, hi = n_coarse;               // largest b with unit_base[b] <= u (skips empty buckets)
+__device__ __forceinline__ uint32_t seg_of_unit(const unsigned long long* unit_base, uint32_t n_seg, uint64_t u) {
+    uint32_t lo = 0, hi = n_seg;                  // largest b with unit_base[b] <= u (skips empty segments)
     while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (unit_base[mid] <= u) lo = mid; else hi = mid; }
     return lo;
 }
-// P2 pass A: per-unit counts of the bucket's regions -> M2[unit][bin] (u32)
-__global__ __launch_bounds__(MS_THREADS) void k_p2_hist(const uint64_t* __restrict__ recs, PartCfg cfg,
-                                                        const unsigned long long* __restrict__ coarse_off,
+// pass A: per-unit bin counts -> M2[unit][bin] (u32)
+__global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restrict__ recs, LevelCfg lv,
+                                                        const unsigned long long* __restrict__ seg_off,
                                                         const unsigned long long* __restrict__ unit_base, uint32_t* __restrict__ m2) {
     __shared__ uint32_t s_hist[NB_MAX];
-    const uint32_t nb = 1u << cfg.g_shift;
-    const uint64_t n_units = unit_base[cfg.n_coarse];
+    const uint64_t n_units = unit_base[lv.n_seg];
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const uint32_t b = bucket_of_unit(unit_base, cfg.n_coarse, u);
-        const uint64_t lo = coarse_off[b] + (u - unit_base[b]) * P2_UNIT;
-        const uint64_t hi = lo + P2_UNIT < coarse_off[b + 1] ? lo + P2_UNIT : coarse_off[b + 1];
-        const uint64_t rbase = (uint64_t)b << cfg.g_shift;
-        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS) s_hist[i] = 0;
+        const uint32_t b = seg_of_unit(unit_base, lv.n_seg, u);
+        const uint64_t lo = seg_off[b] + (u - unit_base[b]) * P2_UNIT;
+        const uint64_t hi = lo + P2_UNIT < seg_off[b + 1] ? lo + P2_UNIT : seg_off[b + 1];
+        for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) s_hist[i] = 0;
         __syncthreads();
         for (uint64_t i = lo + threadIdx.x; i < hi; i += MS_THREADS)
-            atomicAdd(&s_hist[(uint32_t)(region_id(rec_key(recs[i]), cfg.n_regions) - rbase)], 1u);
+            atomicAdd(&s_hist[level_bin(lv, b, region_id(rec_key(recs[i]), lv.n_regions))], 1u);
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS) m2[u * nb + i] = s_hist[i];
+        for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) m2[u * lv.nb + i] = s_hist[i];
         __syncthreads();
     }
 }
-// per region: exclusive prefix of its counts over the bucket's units (in place), region total out
-__global__ __launch_bounds__(256) void k_p2_offsets(uint32_t* __restrict__ m2, PartCfg cfg, const unsigned long long* __restrict__ unit_base,
-                                                    unsigned long long* __restrict__ fine_count) {
+// per output group (segment b, bin): exclusive prefix of its counts over the segment's units
+// (in place), group total out
+__global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, LevelCfg lv, const unsigned long long* __restrict__ unit_base,
+                                                    unsigned long long* __restrict__ group_count) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= cfg.n_regions) return;
-    const uint32_t nb = 1u << cfg.g_shift;
-    const uint32_t b = (uint32_t)(r >> cfg.g_shift), bin = (uint32_t)(r & (nb - 1));
+    if (r >= (uint64_t)lv.n_seg * lv.nb) return;
+    const uint32_t b = (uint32_t)(r / lv.nb), bin = (uint32_t)(r % lv.nb);
     unsigned long long run = 0;
     for (uint64_t u = unit_base[b]; u < unit_base[b + 1]; ++u) {
-        const uint32_t c = m2[u * nb + bin];
-        m2[u * nb + bin] = (uint32_t)run;            // a region holds < 2^32 records of one batch
+        const uint32_t c = m2[u * lv.nb + bin];
+        m2[u * lv.nb + bin] = (uint32_t)run;         // a group holds < 2^32 records of one batch
         run += c;
     }
-    fine_count[r] = run;
+    group_count[r] = run;
 }
-// P2 pass B: records -> grouped by region, private cursors = region_base + unit prefix
-__global__ __launch_bounds__(MS_THREADS) void k_p2_scatter(const uint64_t* __restrict__ recs, PartCfg cfg,
-                                                           const unsigned long long* __restrict__ coarse_off,
+// pass B: records -> grouped by (segment, bin); private cursors = group_base + unit prefix
+__global__ __launch_bounds__(MS_THREADS) void k_lv_scatter(const uint64_t* __restrict__ recs, LevelCfg lv,
+                                                           const unsigned long long* __restrict__ seg_off,
                                                            const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
-                                                           const unsigned long long* __restrict__ region_base, uint64_t* __restrict__ out) {
+                                                           const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out) {
     __shared__ MsShared s;
-    const uint32_t nb = 1u << cfg.g_shift;
-    const uint64_t n_units = unit_base[cfg.n_coarse];
+    const uint32_t nb = lv.nb;
+    const uint64_t n_units = unit_base[lv.n_seg];
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const uint32_t b = bucket_of_unit(unit_base, cfg.n_coarse, u);
-        const uint64_t lo = coarse_off[b] + (u - unit_base[b]) * P2_UNIT;
-        const uint64_t hi = lo + P2_UNIT < coarse_off[b + 1] ? lo + P2_UNIT : coarse_off[b + 1];
-        const uint64_t rbase = (uint64_t)b << cfg.g_shift;
-        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS)
-            s.gbase[i] = (rbase + i < cfg.n_regions) ? region_base[rbase + i] + m2[u * nb + i] : 0ull;
+        const uint32_t b = seg_of_unit(unit_base, lv.n_seg, u);
+        const uint64_t lo = seg_off[b] + (u - unit_base[b]) * P2_UNIT;
+        const uint64_t hi = lo + P2_UNIT < seg_off[b + 1] ? lo + P2_UNIT : seg_off[b + 1];
+        for (uint32_t i = threadIdx.x; i < nb; i += MS_THREADS) s.gbase[i] = group_base[(uint64_t)b * nb + i] + m2[u * nb + i];
         __syncthreads();
         // software pipeline: the next round's records are loaded before this round is split
         uint64_t nxt[MS_ITEMS];
@@ -289,7 +286,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_p2_scatter(const uint64_t* __res
             for (int j = 0; j < MS_ITEMS; ++j) {
                 const uint64_t i = pos + (uint64_t)j * MS_THREADS + threadIdx.x;
                 rec[j] = nxt[j];
-                bin[j] = i < hi ? (uint32_t)(region_id(rec_key(rec[j]), cfg.n_regions) - rbase) : nb;
+                bin[j] = i < hi ? level_bin(lv, b, region_id(rec_key(rec[j]), lv.n_regions)) : nb;
             }
 #pragma unroll
             for (int j = 0; j < MS_ITEMS; ++j) {
@@ -300,6 +297,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_p2_scatter(const uint64_t* __res
         }
     }
 }
+__global__ void k_set2(unsigned long long* p, unsigned long long a, unsigned long long b) { p[0] = a; p[1] = b; }
 
 // multi-block exclusive scan helpers (chunks of SCAN_CHUNK elements per workgroup)
 constexpr uint32_t SCAN_CHUNK = 16384;
@@ -892,72 +890,127 @@ int kq_get_info(kq_handle* h, kq_info* out) {
 }
 
 // ---- count ---------------------------------------------------------------------------------
+// ---- partitioned count: host orchestration -------------------------------------------------------
+struct PartPlan {
+    PartCfg cfg;              // P1 (bases -> coarse buckets)
+    bool two_level;
+    uint64_t n_max, R;
+    uint32_t g1;              // P1 scatter workgroups
+    uint64_t m1_n, m2_n, sums_n, groups_n;
+    // device pointers into h->part
+    uint64_t *recs1, *recs2;
+    unsigned long long *m1, *seg_off, *unit_base, *group_base, *sums, *total;
+    uint32_t* m2;
+};
+static void plan_cfg(const kq_handle* h, PartCfg* cfg) {
+    cfg->n_regions = h->n_regions;
+    uint32_t g = 0;
+    while ((1ull << (2 * g)) < cfg->n_regions) ++g;           // 2^g ~ sqrt(R): balanced fan-outs
+    cfg->g_shift = cfg->n_regions < (uint64_t)NB_MAX ? 0 : g;
+    cfg->n_coarse = (uint32_t)((cfg->n_regions + (1ull << cfg->g_shift) - 1) >> cfg->g_shift);
+    cfg->mode = 0; cfg->map_count = (uint32_t)h->map_count;
+    cfg->map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
+}
+// carve the scratch buffer for a batch of at most n_max records; n_tiles = 0 when the input is records
+static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins) {
+    plan_cfg(h, &p->cfg);
+    p->two_level = p->cfg.g_shift != 0;
+    p->n_max = n_max; p->R = p->cfg.n_regions;
+    p->g1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * 2));
+    p->m1_n = (uint64_t)p1_bins * p->g1 * P1_F;
+    const uint64_t nb_max = std::max<uint64_t>(1ull << p->cfg.g_shift, p->cfg.n_coarse);
+    p->m2_n = (n_max / P2_UNIT + NB_MAX + 2) * nb_max;         // u32 entries, enough for either level
+    p->groups_n = std::max<uint64_t>(p->R, (uint64_t)p->cfg.n_coarse << p->cfg.g_shift) + 2;
+    p->sums_n = std::max(p->m1_n, p->groups_n) / SCAN_CHUNK + 2;
+    const size_t words = (size_t)(2 * n_max + p->m1_n + 2 * (NB_MAX + 2) + p->groups_n + p->sums_n + 4 + (p->m2_n + 1) / 2);
+    int rc = ensure_buf(&h->part, &h->part_bytes, words * 8);
+    if (rc) return rc;
+    p->recs1 = (uint64_t*)h->part;
+    p->recs2 = p->recs1 + n_max;
+    p->m1 = (unsigned long long*)(p->recs2 + n_max);
+    p->seg_off = p->m1 + p->m1_n;
+    p->unit_base = p->seg_off + NB_MAX + 2;
+    p->group_base = p->unit_base + NB_MAX + 2;
+    p->sums = p->group_base + p->groups_n;
+    p->total = p->sums + p->sums_n;
+    p->m2 = (uint32_t*)(p->total + 4);
+    return KQ_OK;
+}
 // exclusive scan of n u64 on the device (in place); *total (device) receives the sum
-static int scan_u64(kq_handle* h, unsigned long long* a, uint64_t n, unsigned long long* sums_scratch, unsigned long long* total) {
+static void scan_u64(kq_handle* h, unsigned long long* a, uint64_t n, unsigned long long* sums_scratch, unsigned long long* total) {
     if (n <= SCAN_CHUNK) {
         hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, a, n, total);
-        return KQ_OK;
+        return;
     }
     const uint64_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)chunks), dim3(1024), 0, h->stream, a, n, sums_scratch);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, sums_scratch, chunks, total);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)chunks), dim3(1024), 0, h->stream, a, n, sums_scratch);
-    return KQ_OK;
+}
+// P1 on bases with the given bin function; afterwards p->seg_off[0..bins] are the bucket offsets
+// (seg_off[bins] = number of records) and `out` holds the records grouped by bin
+static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t* ab, uint64_t lead, uint64_t len, uint64_t* out) {
+    hipLaunchKernelGGL(k_p1_hist, dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, p->g1, p->m1);
+    scan_u64(h, p->m1, (uint64_t)cfg.n_coarse * p->g1 * P1_F, p->sums, p->total);
+    hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, p->m1, p->total, cfg, p->g1, p->seg_off);
+    hipLaunchKernelGGL(k_p1_scatter, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, p->m1, out);
+}
+// one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
+// afterwards p->group_base[0..n_seg*nb] are the output offsets
+static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint64_t* in, uint64_t* out) {
+    const uint64_t groups = (uint64_t)lv.n_seg * lv.nb;
+    hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, lv, p->unit_base);
+    hipLaunchKernelGGL(k_lv_hist, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
+    hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);
+    scan_u64(h, p->group_base, groups + 1, p->sums, p->total + 1);
+    hipLaunchKernelGGL(k_lv_scatter, dim3(h->n_cu * 2), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2,
+                       p->group_base, out);
+}
+static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0;
+    return lv;
+}
+static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift;
+    return lv;
+}
+static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const unsigned long long* base) {
+    hipLaunchKernelGGL(k_count_regions, dim3(grid_for(h, p->R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted, base,
+                       h->table_empty ? 1 : 0);
 }
 
-// partitioned count of one batch: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
+// partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
 static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len) {
-    PartCfg cfg;
-    cfg.n_regions = h->n_regions;
-    uint32_t g = 0;
-    while ((1ull << (2 * g)) < cfg.n_regions) ++g;            // 2^g ~ sqrt(R): balanced fan-outs
-    cfg.g_shift = cfg.n_regions < (uint64_t)NB_MAX ? 0 : g;
-    cfg.n_coarse = (uint32_t)((cfg.n_regions + (1ull << cfg.g_shift) - 1) >> cfg.g_shift);
-    const bool two_level = cfg.g_shift != 0;
-    const uint64_t n_max = len;                                // >= number of k-mers
-    const uint64_t R = cfg.n_regions;
-    const uint64_t n_tiles = n_tiles_of(lead, len);
-    const uint32_t g1 = (uint32_t)std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * 2);   // P1 scatter workgroups (72 KiB LDS: 2 per CU)
-    const uint64_t m1_n = (uint64_t)cfg.n_coarse * g1 * P1_F;
-    const uint32_t nb2 = 1u << cfg.g_shift;
-    const uint64_t max_units = n_max / P2_UNIT + cfg.n_coarse + 2;
-    const uint64_t m2_n = two_level ? max_units * nb2 : 0;     // u32 entries
-    const uint64_t sums_n = std::max(m1_n, R + 2) / SCAN_CHUNK + 2;
-    // layout (u64 words): recs1[n_max] recs2[n_max] m1[m1_n] coarse_off[NB_MAX+2] unit_base[NB_MAX+2]
-    //                     region_base[R+2] sums[sums_n] total[2] m2[(m2_n+1)/2]
-    const size_t words = (size_t)(2 * n_max + m1_n + 2 * (NB_MAX + 2) + (R + 2) + sums_n + 2 + (m2_n + 1) / 2);
-    int rc = ensure_buf(&h->part, &h->part_bytes, words * 8);
+    PartPlan p;
+    PartCfg c0; plan_cfg(h, &c0);
+    int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), c0.n_coarse);
     if (rc) return rc;
-    uint64_t* recs1 = (uint64_t*)h->part;
-    uint64_t* recs2 = recs1 + n_max;
-    unsigned long long* m1 = (unsigned long long*)(recs2 + n_max);
-    unsigned long long* coarse_off = m1 + m1_n;
-    unsigned long long* unit_base = coarse_off + NB_MAX + 2;
-    unsigned long long* region_base = unit_base + NB_MAX + 2;
-    unsigned long long* sums = region_base + R + 2;
-    unsigned long long* total = sums + sums_n;
-    uint32_t* m2 = (uint32_t*)(total + 2);
-    // P1
-    hipLaunchKernelGGL(k_p1_hist, dim3(g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, g1, m1);
-    rc = scan_u64(h, m1, m1_n, sums, total);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, m1, total, cfg, g1, coarse_off);
-    hipLaunchKernelGGL(k_p1_scatter, dim3(g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, m1, recs1);
-    const uint64_t* sorted = recs1;
-    const unsigned long long* base = coarse_off;
-    if (two_level) {
-        const int grid_ms = h->n_cu * 2;
-        hipLaunchKernelGGL(k_p2_units, dim3(1), dim3(1024), 0, h->stream, coarse_off, cfg, unit_base);
-        hipLaunchKernelGGL(k_p2_hist, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, recs1, cfg, coarse_off, unit_base, m2);
-        hipLaunchKernelGGL(k_p2_offsets, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, h->stream, m2, cfg, unit_base, region_base);
-        HIPC(hipMemsetAsync(region_base + R, 0, 8, h->stream));
-        rc = scan_u64(h, region_base, R + 1, sums, total + 1);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_p2_scatter, dim3(grid_ms), dim3(MS_THREADS), 0, h->stream, recs1, cfg, coarse_off, unit_base, m2, region_base, recs2);
-        sorted = recs2;
-        base = region_base;
+    run_p1(h, &p, p.cfg, ab, lead, len, p.recs1);
+    if (p.two_level) {
+        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, p.recs2);
+        run_p3(h, &p, p.recs2, p.group_base);
+    } else {
+        run_p3(h, &p, p.recs1, p.seg_off);                     // bins were the regions themselves
     }
-    hipLaunchKernelGGL(k_count_regions, dim3(grid_for(h, R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted, base, h->table_empty ? 1 : 0);
+    HIPC(hipGetLastError());
+    return KQ_OK;
+}
+// partitioned count of n packed records already on the device (multi-GPU receive side)
+static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, uint64_t n) {
+    PartPlan p;
+    int rc = plan_alloc(h, &p, n, 0, 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, h->stream, p.seg_off, 0ull, (unsigned long long)n);
+    run_level(h, &p, level_flat_to_coarse(p.cfg), d_recs, p.recs1);        // group_base = coarse offsets
+    if (p.two_level) {
+        // the coarse offsets become the segment table of the next level
+        HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)(p.cfg.n_coarse + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
+        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, p.recs2);
+        run_p3(h, &p, p.recs2, p.group_base);
+    } else {
+        run_p3(h, &p, p.recs1, p.group_base);
+    }
     HIPC(hipGetLastError());
     return KQ_OK;
 }
@@ -1078,6 +1131,44 @@ int kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, int
                        (uint32_t)n_parts, cursor, d_keys, d_edges, cap);
     HIPC(hipStreamSynchronize(h->stream));   // off[] is a stack vector: keep it alive until the copy is done
     return KQ_OK;
+}
+
+int kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts, uint64_t* d_recs, uint64_t cap,
+                       uint64_t* part_counts) {
+    if (!h || !part_counts || n_parts < 1 || n_parts > h->map_count || n_parts >= NB_MAX || (!d_bases && len))
+        return fail(KQ_ERR_INVALID, "bad argument");
+    if (h->k > PART_MAX_K) return fail(KQ_ERR_INVALID, "packed 8-byte records need k <= %d (use kq_emit_partitioned_dev)", PART_MAX_K);
+    HIPC(hipSetDevice(h->device));
+    for (int i = 0; i < n_parts; ++i) part_counts[i] = 0;
+    if (len < (uint64_t)h->k) return KQ_OK;
+    if (cap < len - h->k + 1 || !d_recs) return fail(KQ_ERR_CAPACITY, "record buffer too small: need room for %llu records",
+                                                       (unsigned long long)(len - h->k + 1));
+    const uint8_t* ab; uint64_t lead;
+    aligned_view(d_bases, &ab, &lead);
+    PartPlan p;
+    int rc = plan_alloc(h, &p, 0, n_tiles_of(lead, len), (uint32_t)n_parts);
+    if (rc) return rc;
+    PartCfg cfg = p.cfg;
+    cfg.mode = 1; cfg.n_coarse = (uint32_t)n_parts;
+    run_p1(h, &p, cfg, ab, lead, len, d_recs);
+    std::vector<unsigned long long> off((size_t)n_parts + 1);
+    HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n_parts; ++i) part_counts[i] = off[(size_t)i + 1] - off[(size_t)i];
+    return KQ_OK;
+}
+
+int kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n) {
+    if (!h || (!d_recs && n)) return fail(KQ_ERR_INVALID, "null argument");
+    if (h->k > PART_MAX_K) return fail(KQ_ERR_INVALID, "packed 8-byte records need k <= %d (use kq_insert_records_dev)", PART_MAX_K);
+    HIPC(hipSetDevice(h->device));
+    if (!n) return KQ_OK;
+    int rc = reserve(h, n, n);
+    if (rc) return rc;
+    if (h->n_regions > (1ull << 20)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
+    rc = count_partitioned_records(h, d_recs, n);
+    h->table_empty = false;
+    return rc;
 }
 
 int kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d_edges, uint64_t n) {

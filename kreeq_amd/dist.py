@@ -35,26 +35,39 @@ class GpuEngine:
     def __init__(self, k, map_count, device_index, capacity_hint=0):
         from .capi import KreeqDB
 
+        self.k = k
         self.device = torch.device("cuda", device_index)
         self.db = KreeqDB(k, map_count, device=device_index, capacity_hint=capacity_hint)
-        self.db.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # kernels, torch ops on the exchanged tensors and the RCCL collectives must share ONE stream;
+        # the legacy null stream cannot be handed to the library, so fall back to a dedicated stream
+        cur = torch.cuda.current_stream(self.device)
+        self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(self.device)
+        self.db.set_stream(self.stream.cuda_stream)
         self._keys = self._edges = None
 
     def emit_partitioned(self, bases: torch.Tensor, n_parts: int):
+        """-> ([payload tensors grouped by owner part], per-part record counts)"""
         n = bases.numel()
         if self._keys is None or self._keys.numel() < n:
             self._keys = torch.empty(n, dtype=torch.int64, device=self.device)
-            self._edges = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._edges = torch.empty(n, dtype=torch.uint8, device=self.device) if self.k > 28 else None
+        if self.k <= 28:        # packed 8-byte records: one array to exchange, atomic-free receive side
+            counts = self.db.emit_packed_dev(bases.data_ptr(), n, n_parts, self._keys.data_ptr(), n)
+            tot = int(counts.sum())
+            return [self._keys[:tot]], counts.astype(np.int64)
         counts = self.db.emit_partitioned_dev(bases.data_ptr(), n, n_parts, self._keys.data_ptr(), self._edges.data_ptr(), n)
         tot = int(counts.sum())
-        return self._keys[:tot], self._edges[:tot], counts.astype(np.int64)
+        return [self._keys[:tot], self._edges[:tot]], counts.astype(np.int64)
 
     def count(self, bases: torch.Tensor):
         """fused K1+K2 (no record materialisation): the single-GPU path"""
         self.db.count_batch_dev(bases.data_ptr(), bases.numel())
 
-    def insert(self, keys: torch.Tensor, edges: torch.Tensor):
-        self.db.insert_records_dev(keys.data_ptr(), edges.data_ptr(), keys.numel())
+    def insert(self, payload):
+        if len(payload) == 1:
+            self.db.insert_packed_dev(payload[0].data_ptr(), payload[0].numel())
+        else:
+            self.db.insert_records_dev(payload[0].data_ptr(), payload[1].data_ptr(), payload[0].numel())
 
     def lookup(self, bases: torch.Tensor, map_lo, map_hi, cov_cutoff=0):
         ctr = torch.zeros(3, dtype=torch.int64, device=self.device)
@@ -73,47 +86,63 @@ class GpuEngine:
 
 
 class ShardedCounter:
-    def __init__(self, engine, k, map_count=128, group=None):
+    def __init__(self, engine, k, map_count=128, group=None, sharded_path=False):
+        """sharded_path=True runs emit -> (exchange) -> insert even on one rank (rehearsal of the N>1 code)"""
         self.engine, self.k, self.map_count, self.group = engine, k, map_count, group
+        self.sharded_path = sharded_path
+        self.force_exchange = False
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if self.world > map_count:
             raise ValueError("more ranks than maps")
         self.map_lo, self.map_hi = owner_range(self.rank, self.world, map_count)
 
+    def _stream_ctx(self):
+        import contextlib
+
+        st = getattr(self.engine, "stream", None)
+        return torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+
     def count_batch(self, bases: torch.Tensor):
         """bases: this rank's read batch (uint8 tensor on the engine's device). Returns #records received."""
-        if self.world == 1 and hasattr(self.engine, "count"):
+        with self._stream_ctx():
+            return self._count_batch(bases)
+
+    def _count_batch(self, bases: torch.Tensor):
+        if self.world == 1 and hasattr(self.engine, "count") and not self.sharded_path:
             self.engine.count(bases)
             return None
-        keys, edges, send_counts = self.engine.emit_partitioned(bases, self.world)
-        if self.world == 1:
-            self.engine.insert(keys, edges)
+        payload, send_counts = self.engine.emit_partitioned(bases, self.world)
+        if self.world == 1 and not self.force_exchange:
+            self.engine.insert(payload)
             return int(send_counts.sum())
-        dev = keys.device
+        dev = payload[0].device
         sc = torch.from_numpy(send_counts).to(dev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)                 # how many records each peer sends me
         recv_counts = rc.cpu().numpy()
         n_recv = int(recv_counts.sum())
-        rk = torch.empty(n_recv, dtype=keys.dtype, device=dev)
-        re = torch.empty(n_recv, dtype=edges.dtype, device=dev)
-        dist.all_to_all_single(rk, keys, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(), group=self.group)
-        dist.all_to_all_single(re, edges, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(), group=self.group)
-        self.engine.insert(rk, re)
+        received = []
+        for t in payload:                                                # all-to-all(v), one per payload array
+            r = torch.empty(n_recv, dtype=t.dtype, device=dev)
+            dist.all_to_all_single(r, t, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(), group=self.group)
+            received.append(r)
+        self.engine.insert(received)
         return n_recv
 
     def validate(self, bases: torch.Tensor, cov_cutoff=0):
         """every rank passes the SAME assembly sequence; returns the global (missing, total, edgeMissing)"""
-        ctr = self.engine.lookup(bases, self.map_lo, self.map_hi, cov_cutoff)
-        if self.world > 1:
-            dist.all_reduce(ctr, op=dist.ReduceOp.SUM, group=self.group)
-        return ctr.cpu().numpy().astype(np.uint64)
+        with self._stream_ctx():
+            ctr = self.engine.lookup(bases, self.map_lo, self.map_hi, cov_cutoff)
+            if self.world > 1:
+                dist.all_reduce(ctr, op=dist.ReduceOp.SUM, group=self.group)
+            return ctr.cpu().numpy().astype(np.uint64)
 
     def summary(self):
-        v = self.engine.summary_vector()
-        if self.world > 1:
-            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
-        t = v.cpu().tolist()
+        with self._stream_ctx():
+            v = self.engine.summary_vector()
+            if self.world > 1:
+                dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            t = v.cpu().tolist()
         space = (1 << (2 * self.k)) if self.k < 32 else 0
         return {"total": t[0], "unique": t[1], "distinct": t[2], "missing": (space - t[2]) % (1 << 64), "edges": t[3]}

@@ -27,9 +27,10 @@ class HostEngine:
         owner = owner_of(keys, n_parts, self.map_count)
         order = np.argsort(owner, kind="stable")
         counts = np.bincount(owner, minlength=n_parts).astype(np.int64)
-        return torch.from_numpy(keys[order].astype(np.int64)), torch.from_numpy(edges[order]), counts
+        return [torch.from_numpy(keys[order].astype(np.int64)), torch.from_numpy(edges[order])], counts
 
-    def insert(self, keys, edges):
+    def insert(self, payload):
+        keys, edges = payload
         self.db.insert_records(keys.numpy().astype(np.uint64), edges.numpy())
 
     def lookup(self, bases, map_lo, map_hi, cov_cutoff=0):
