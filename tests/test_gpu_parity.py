@@ -405,3 +405,35 @@ def test_sharded_counter_single_rank(kq, O):
     ctr = sc.validate(torch.frombuffer(bytearray(genome), dtype=torch.uint8).cuda())
     cc, _ = cpu.validate_sequence(genome)
     assert ctr.tolist() == cc.tolist()
+
+
+def test_sharded_counter_rccl_world1(kq, O):
+    """the exchange code (all_to_all_single with split sizes, all_reduce) over the nccl (= RCCL) backend,
+    world size 1 -- the only RCCL configuration a one-GPU box can run"""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from kreeq_amd.dist import GpuEngine, ShardedCounter
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        batch, genome = H.synth_reads(9000, 150, 50000, seed=92, err=0.01, n_rate=0.002)
+        cpu = O.OracleDB(21, 128)
+        cpu.count_batch(batch, threads=8)
+        eng = GpuEngine(21, 128, 0)
+        sc = ShardedCounter(eng, 21, 128, sharded_path=True)
+        sc.force_exchange = True
+        sc.count_batch(torch.frombuffer(bytearray(batch), dtype=torch.uint8).cuda())
+        eng.sync()
+        assert sc.summary() == cpu.summary()
+        ctr = sc.validate(torch.frombuffer(bytearray(genome), dtype=torch.uint8).cuda())
+        cc, _ = cpu.validate_sequence(genome)
+        assert ctr.tolist() == cc.tolist()
+    finally:
+        dist.destroy_process_group()
