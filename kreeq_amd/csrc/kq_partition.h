@@ -11,6 +11,9 @@
 //
 // Record (k <= 28): key in bits 0..2k-1; bits 56..58 = index of the fw edge (0..3, 7 = none),
 // bits 59..61 = index of the bw edge (0..3, 7 = none): a k-mer instance has at most one of each.
+// WIDE records (k = 29..32, or records handed in by a caller): the u64 is the whole key and the
+// edge information travels in a parallel u8 array that is split in lockstep ("aux"): either the
+// same 6-bit index pair (AUX_IDX6) or the reference edge byte of include/kreeq.h:6-18 (AUX_EDGE_BYTE).
 #pragma once
 #include "kq_device.h"
 
@@ -21,7 +24,8 @@ constexpr int MS_ITEMS = 16;
 constexpr int MS_TILE = MS_THREADS * MS_ITEMS;   // 4096 records per multisplit round
 constexpr int NB_MAX = 2048;                     // bins of one split incl. the discard bin: fan-out <= NB_MAX - 1
 constexpr int REC_EDGE_SHIFT = 56;
-constexpr int PART_MAX_K = 28;
+constexpr int PART_MAX_K = 28;                   // packed 8-byte records up to here, WIDE above
+constexpr int AUX_IDX6 = 0, AUX_EDGE_BYTE = 1;
 
 struct PartCfg {
     uint64_t n_regions;   // R
@@ -46,11 +50,22 @@ __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, ui
 }
 
 // fw/bw edge indices as src/graph-builder.cpp:98-110 assigns them
-__device__ __forceinline__ uint64_t rec_pack(uint64_t key, bool is_fw, uint32_t prev, uint32_t next) {
+__device__ __forceinline__ uint32_t edge_idx6(bool is_fw, uint32_t prev, uint32_t next) {
     uint32_t f, b;
     if (is_fw) { f = next < 4 ? next : 7u; b = prev < 4 ? prev : 7u; }
     else       { f = prev < 4 ? 3u - prev : 7u; b = next < 4 ? 3u - next : 7u; }
-    return key | ((uint64_t)(f | (b << 3)) << REC_EDGE_SHIFT);
+    return f | (b << 3);
+}
+__device__ __forceinline__ uint64_t rec_pack(uint64_t key, bool is_fw, uint32_t prev, uint32_t next) {
+    return key | ((uint64_t)edge_idx6(is_fw, prev, next) << REC_EDGE_SHIFT);
+}
+__device__ __forceinline__ uint64_t idx6_to_pack(uint32_t v) {
+    const uint32_t f = v & 7u, b = (v >> 3) & 7u;
+    return (f < 4 ? 1ull << (8 * f) : 0ull) | (b < 4 ? 1ull << (8 * (4 + b)) : 0ull);
+}
+__device__ __forceinline__ uint32_t idx6_to_edge_byte(uint32_t v) {
+    const uint32_t f = v & 7u, b = (v >> 3) & 7u;
+    return (f < 4 ? 1u << (7 - f) : 0u) | (b < 4 ? 1u << (7 - (4 + b)) : 0u);
 }
 __device__ __forceinline__ uint64_t rec_key(uint64_t rec) { return rec & ((1ull << REC_EDGE_SHIFT) - 1); }
 // packed u8x8 increment (byte e = edge e) of a record
@@ -63,9 +78,10 @@ __device__ __forceinline__ uint64_t region_id(uint64_t key, uint64_t n_regions) 
 struct MsShared {
     uint64_t stage[MS_TILE];                 // 32 KiB
     uint16_t sbin[MS_TILE];                  //  8 KiB
+    uint8_t  saux[MS_TILE];                  //  4 KiB   (WIDE records only)
     uint32_t hist[NB_MAX];                   //  8 KiB
     uint32_t loff[NB_MAX];                   //  8 KiB
-    unsigned long long gbase[NB_MAX];        // 16 KiB      (72 KiB in all: two workgroups per CU)
+    unsigned long long gbase[NB_MAX];        // 16 KiB      (76 KiB in all: two workgroups per CU)
     uint32_t wave_sum[MS_THREADS / 64];
 };
 constexpr int MS_BINS_PER_THREAD = NB_MAX / MS_THREADS;
@@ -94,8 +110,10 @@ __device__ __forceinline__ void ms_scan(MsShared& s, uint32_t nb) {
 // s.gbase[b] is the workgroup's PRIVATE running output cursor of bin b (set by the caller before
 // the first round, advanced here), so a round needs no global atomic at all; records of a bin
 // land contiguously at the cursor.  All threads of the block must call it.  nb < NB_MAX.
-__device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&rec)[MS_ITEMS], const uint32_t (&bin)[MS_ITEMS], uint32_t nb,
-                                                 uint64_t* __restrict__ out) {
+template <bool WIDE>
+__device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&rec)[MS_ITEMS], const uint32_t (&aux)[MS_ITEMS],
+                                                 const uint32_t (&bin)[MS_ITEMS], uint32_t nb,
+                                                 uint64_t* __restrict__ out, uint8_t* __restrict__ out_aux) {
     const int tid = threadIdx.x;
     for (uint32_t b = tid; b <= nb; b += MS_THREADS) s.hist[b] = 0;
     __syncthreads();
@@ -109,12 +127,15 @@ __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&r
         const uint32_t p = s.loff[bin[i]] + rank[i];
         s.stage[p] = rec[i];
         s.sbin[p] = (uint16_t)bin[i];
+        if (WIDE) s.saux[p] = (uint8_t)aux[i];
     }
     __syncthreads();
     const uint32_t total = s.loff[nb];           // records in front of the discard bin
     for (uint32_t j = tid; j < total; j += MS_THREADS) {
         const uint32_t b = s.sbin[j];
-        out[s.gbase[b] + (j - s.loff[b])] = s.stage[j];
+        const uint64_t g = s.gbase[b] + (j - s.loff[b]);
+        out[g] = s.stage[j];
+        if (WIDE) out_aux[g] = s.saux[j];
     }
     __syncthreads();
     // advance the cursors; the same thread zeroes hist[b] at the start of the next round

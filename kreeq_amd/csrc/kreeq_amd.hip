@@ -108,34 +108,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_emit_write(const uint8_t* __re
     }
 }
 
-// K1 for the multi-GPU exchange: pass A histogram of owner parts, pass B scatter by part.
-__device__ __forceinline__ uint32_t owner_part(uint64_t key, uint32_t map_count, uint32_t n_parts) {
-    uint32_t m = (uint32_t)(key % map_count);            // src/graph-builder.cpp:95
-    return (uint32_t)(((uint64_t)m * n_parts) / map_count);
-}
-__global__ __launch_bounds__(TILE_THREADS) void k_part_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
-                                                             uint32_t map_count, uint32_t n_parts, unsigned long long* part_counts) {
-    extern __shared__ unsigned long long s_hist[];
-    for (uint32_t i = threadIdx.x; i < n_parts; i += blockDim.x) s_hist[i] = 0;
-    __syncthreads();
-    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
-        atomicAdd(&s_hist[owner_part(fw < rv ? fw : rv, map_count, n_parts)], 1ull);
-    });
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_parts; i += blockDim.x)
-        if (s_hist[i]) atomicAdd(&part_counts[i], s_hist[i]);
-}
-__global__ __launch_bounds__(TILE_THREADS) void k_part_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
-                                                                uint32_t map_count, uint32_t n_parts, unsigned long long* part_cursor,
-                                                                uint64_t* keys, uint8_t* edges, uint64_t cap) {
-    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
-        const bool is_fw = fw < rv;
-        const uint64_t key = is_fw ? fw : rv;
-        uint64_t o = atomicAdd(&part_cursor[owner_part(key, map_count, n_parts)], 1ull);
-        if (o < cap) { keys[o] = key; edges[o] = pack_to_edge_byte(edge_pack(is_fw, prev, next)); }
-    });
-}
-
 // ------------------------------------------------------------------------------------------------
 // partitioned count path (kq_partition.h)
 // ------------------------------------------------------------------------------------------------
@@ -179,9 +151,10 @@ __global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const un
     if (b == cfg.n_coarse) coarse_off[b] = *total;
 }
 // P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
+template <bool WIDE>
 __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
                                                              PartCfg cfg, const unsigned long long* __restrict__ m1,
-                                                             uint64_t* __restrict__ recs) {
+                                                             uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
     __shared__ MsShared s;
@@ -194,14 +167,21 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __re
         tile_store(nxt, lo_valid, hi_valid, tile, s_codes, s_inv);        // barrier inside (covers the cursor init)
         if (tile + gridDim.x < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + gridDim.x);   // in flight during the split
         uint64_t rec[MS_ITEMS];
-        uint32_t bin[MS_ITEMS];
+        uint32_t aux[MS_ITEMS], bin[MS_ITEMS];
         tile_lane_scan_all(s_codes, s_inv, k, [&](int i, bool valid, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
             const bool is_fw = fw < rv;
             const uint64_t key = is_fw ? fw : rv;
-            rec[i] = rec_pack(key, is_fw, prev, next);
+            if (WIDE) {
+                rec[i] = key;
+                const uint32_t e = edge_idx6(is_fw, prev, next);
+                aux[i] = aux_fmt == AUX_IDX6 ? e : idx6_to_edge_byte(e);
+            } else {
+                rec[i] = rec_pack(key, is_fw, prev, next);
+                aux[i] = 0;
+            }
             bin[i] = valid ? p1_bin(cfg, key) : cfg.n_coarse;
         });
-        block_multisplit(s, rec, bin, cfg.n_coarse, recs);   // ends with a barrier
+        block_multisplit<WIDE>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux);   // ends with a barrier
     }
 }
 
@@ -225,6 +205,7 @@ __device__ __forceinline__ uint32_t seg_of_unit(const unsigned long long* unit_b
     return lo;
 }
 // pass A: per-unit bin counts -> M2[unit][bin] (u32)
+template <bool WIDE>
 __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restrict__ recs, LevelCfg lv,
                                                         const unsigned long long* __restrict__ seg_off,
                                                         const unsigned long long* __restrict__ unit_base, uint32_t* __restrict__ m2) {
@@ -237,7 +218,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
         for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) s_hist[i] = 0;
         __syncthreads();
         for (uint64_t i = lo + threadIdx.x; i < hi; i += MS_THREADS)
-            atomicAdd(&s_hist[level_bin(lv, b, region_id(rec_key(recs[i]), lv.n_regions))], 1u);
+            atomicAdd(&s_hist[level_bin(lv, b, region_id(WIDE ? recs[i] : rec_key(recs[i]), lv.n_regions))], 1u);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) m2[u * lv.nb + i] = s_hist[i];
         __syncthreads();
@@ -259,10 +240,12 @@ __global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, L
     group_count[r] = run;
 }
 // pass B: records -> grouped by (segment, bin); private cursors = group_base + unit prefix
-__global__ __launch_bounds__(MS_THREADS) void k_lv_scatter(const uint64_t* __restrict__ recs, LevelCfg lv,
+template <bool WIDE>
+__global__ __launch_bounds__(MS_THREADS) void k_lv_scatter(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
                                                            const unsigned long long* __restrict__ seg_off,
                                                            const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
-                                                           const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out) {
+                                                           const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out,
+                                                           uint8_t* __restrict__ out_aux) {
     __shared__ MsShared s;
     const uint32_t nb = lv.nb;
     const uint64_t n_units = unit_base[lv.n_seg];
@@ -274,26 +257,30 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_scatter(const uint64_t* __res
         __syncthreads();
         // software pipeline: the next round's records are loaded before this round is split
         uint64_t nxt[MS_ITEMS];
+        uint32_t nxt_aux[MS_ITEMS];
 #pragma unroll
         for (int j = 0; j < MS_ITEMS; ++j) {
             const uint64_t i = lo + (uint64_t)j * MS_THREADS + threadIdx.x;
             nxt[j] = i < hi ? recs[i] : 0;
+            nxt_aux[j] = (WIDE && i < hi) ? recs_aux[i] : 0;
         }
         for (uint64_t pos = lo; pos < hi; pos += MS_TILE) {
             uint64_t rec[MS_ITEMS];
-            uint32_t bin[MS_ITEMS];
+            uint32_t aux[MS_ITEMS], bin[MS_ITEMS];
 #pragma unroll
             for (int j = 0; j < MS_ITEMS; ++j) {
                 const uint64_t i = pos + (uint64_t)j * MS_THREADS + threadIdx.x;
                 rec[j] = nxt[j];
-                bin[j] = i < hi ? level_bin(lv, b, region_id(rec_key(rec[j]), lv.n_regions)) : nb;
+                aux[j] = nxt_aux[j];
+                bin[j] = i < hi ? level_bin(lv, b, region_id(WIDE ? rec[j] : rec_key(rec[j]), lv.n_regions)) : nb;
             }
 #pragma unroll
             for (int j = 0; j < MS_ITEMS; ++j) {
                 const uint64_t i = pos + MS_TILE + (uint64_t)j * MS_THREADS + threadIdx.x;
                 nxt[j] = i < hi ? recs[i] : 0;
+                nxt_aux[j] = (WIDE && i < hi) ? recs_aux[i] : 0;
             }
-            block_multisplit(s, rec, bin, nb, out);
+            block_multisplit<WIDE>(s, rec, aux, bin, nb, out, out_aux);
         }
     }
 }
@@ -338,8 +325,9 @@ __global__ __launch_bounds__(1024) void k_scan_apply(unsigned long long* __restr
 // records of the region are applied with LDS atomics (same two-tier rule as table_add), and the
 // image is streamed back.  Global atomics only for the rare high-copy tier and the two totals.
 constexpr int P3_THREADS = 512;
-__global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const uint64_t* __restrict__ recs,
-                                                              const unsigned long long* __restrict__ region_base, int table_is_empty) {
+template <bool WIDE>
+__global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
+                                                              int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty) {
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
     __shared__ unsigned long long s_new, s_kmers;
     const int tid = threadIdx.x;
@@ -358,8 +346,8 @@ __global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const
         uint32_t n_new = 0, n_ok = 0;
         for (uint64_t i = lo + tid; i < hi; i += P3_THREADS) {
             const uint64_t rec = recs[i];
-            const uint64_t key = rec_key(rec);
-            const uint64_t pack = rec_edge_pack(rec);
+            const uint64_t key = WIDE ? rec : rec_key(rec);
+            const uint64_t pack = WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(recs_aux[i]) : edge_byte_to_pack(recs_aux[i])) : rec_edge_pack(rec);
             const uint32_t off = (uint32_t)table_hash(key) & (REGION_SLOTS - 1);
             uint64_t* slot = nullptr;
             for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
@@ -899,6 +887,7 @@ struct PartPlan {
     uint64_t m1_n, m2_n, sums_n, groups_n;
     // device pointers into h->part
     uint64_t *recs1, *recs2;
+    uint8_t *aux1, *aux2;     // WIDE records: edge bytes travelling with recs1 / recs2
     unsigned long long *m1, *seg_off, *unit_base, *group_base, *sums, *total;
     uint32_t* m2;
 };
@@ -922,12 +911,15 @@ static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tile
     p->m2_n = (n_max / P2_UNIT + NB_MAX + 2) * nb_max;         // u32 entries, enough for either level
     p->groups_n = std::max<uint64_t>(p->R, (uint64_t)p->cfg.n_coarse << p->cfg.g_shift) + 2;
     p->sums_n = std::max(p->m1_n, p->groups_n) / SCAN_CHUNK + 2;
-    const size_t words = (size_t)(2 * n_max + p->m1_n + 2 * (NB_MAX + 2) + p->groups_n + p->sums_n + 4 + (p->m2_n + 1) / 2);
+    const uint64_t aux_words = (n_max + 7) / 8 + 1;
+    const size_t words = (size_t)(2 * n_max + 2 * aux_words + p->m1_n + 2 * (NB_MAX + 2) + p->groups_n + p->sums_n + 4 + (p->m2_n + 1) / 2);
     int rc = ensure_buf(&h->part, &h->part_bytes, words * 8);
     if (rc) return rc;
     p->recs1 = (uint64_t*)h->part;
     p->recs2 = p->recs1 + n_max;
-    p->m1 = (unsigned long long*)(p->recs2 + n_max);
+    p->aux1 = (uint8_t*)(p->recs2 + n_max);
+    p->aux2 = p->aux1 + aux_words * 8;
+    p->m1 = (unsigned long long*)(p->aux2 + aux_words * 8);
     p->seg_off = p->m1 + p->m1_n;
     p->unit_base = p->seg_off + NB_MAX + 2;
     p->group_base = p->unit_base + NB_MAX + 2;
@@ -949,23 +941,29 @@ static void scan_u64(kq_handle* h, unsigned long long* a, uint64_t n, unsigned l
 }
 // P1 on bases with the given bin function; afterwards p->seg_off[0..bins] are the bucket offsets
 // (seg_off[bins] = number of records) and `out` holds the records grouped by bin
-static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t* ab, uint64_t lead, uint64_t len, uint64_t* out) {
+static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t* ab, uint64_t lead, uint64_t len, uint64_t* out,
+                   uint8_t* out_aux, int aux_fmt) {
     hipLaunchKernelGGL(k_p1_hist, dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, p->g1, p->m1);
     scan_u64(h, p->m1, (uint64_t)cfg.n_coarse * p->g1 * P1_F, p->sums, p->total);
     hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, p->m1, p->total, cfg, p->g1, p->seg_off);
-    hipLaunchKernelGGL(k_p1_scatter, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, p->m1, out);
+    if (out_aux) hipLaunchKernelGGL(k_p1_scatter<true>, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, p->m1, out, out_aux, aux_fmt);
+    else hipLaunchKernelGGL(k_p1_scatter<false>, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, p->m1, out, out_aux, aux_fmt);
 }
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
 // afterwards p->group_base[0..n_seg*nb] are the output offsets
-static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint64_t* in, uint64_t* out) {
+static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint64_t* in, const uint8_t* in_aux, uint64_t* out, uint8_t* out_aux) {
+    const bool wide = in_aux != nullptr;
     const uint64_t groups = (uint64_t)lv.n_seg * lv.nb;
     hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, lv, p->unit_base);
-    hipLaunchKernelGGL(k_lv_hist, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    if (wide) hipLaunchKernelGGL(k_lv_hist<true>, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    else hipLaunchKernelGGL(k_lv_hist<false>, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
     hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);
     scan_u64(h, p->group_base, groups + 1, p->sums, p->total + 1);
-    hipLaunchKernelGGL(k_lv_scatter, dim3(h->n_cu * 2), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2,
-                       p->group_base, out);
+    if (wide) hipLaunchKernelGGL(k_lv_scatter<true>, dim3(h->n_cu * 2), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, p->unit_base,
+                                 p->m2, p->group_base, out, out_aux);
+    else hipLaunchKernelGGL(k_lv_scatter<false>, dim3(h->n_cu * 2), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, p->unit_base,
+                            p->m2, p->group_base, out, out_aux);
 }
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0;
@@ -975,9 +973,11 @@ static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift;
     return lv;
 }
-static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const unsigned long long* base) {
-    hipLaunchKernelGGL(k_count_regions, dim3(grid_for(h, p->R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted, base,
-                       h->table_empty ? 1 : 0);
+static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint8_t* sorted_aux, int aux_fmt, const unsigned long long* base) {
+    if (sorted_aux) hipLaunchKernelGGL(k_count_regions<true>, dim3(grid_for(h, p->R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted,
+                                       sorted_aux, aux_fmt, base, h->table_empty ? 1 : 0);
+    else hipLaunchKernelGGL(k_count_regions<false>, dim3(grid_for(h, p->R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted, sorted_aux,
+                            aux_fmt, base, h->table_empty ? 1 : 0);
 }
 
 // partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
@@ -986,30 +986,36 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     PartCfg c0; plan_cfg(h, &c0);
     int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), c0.n_coarse);
     if (rc) return rc;
-    run_p1(h, &p, p.cfg, ab, lead, len, p.recs1);
+    const bool wide = h->k > PART_MAX_K;                       // 8-byte packed records up to k = 28, key + edge byte above
+    uint8_t* a1 = wide ? p.aux1 : nullptr;
+    uint8_t* a2 = wide ? p.aux2 : nullptr;
+    run_p1(h, &p, p.cfg, ab, lead, len, p.recs1, a1, AUX_IDX6);
     if (p.two_level) {
-        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, p.recs2);
-        run_p3(h, &p, p.recs2, p.group_base);
+        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
+        run_p3(h, &p, p.recs2, a2, AUX_IDX6, p.group_base);
     } else {
-        run_p3(h, &p, p.recs1, p.seg_off);                     // bins were the regions themselves
+        run_p3(h, &p, p.recs1, a1, AUX_IDX6, p.seg_off);       // bins were the regions themselves
     }
     HIPC(hipGetLastError());
     return KQ_OK;
 }
-// partitioned count of n packed records already on the device (multi-GPU receive side)
-static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, uint64_t n) {
+// partitioned count of n records already on the device (multi-GPU receive side, kq_insert_records_dev).
+// d_aux == nullptr: packed 8-byte records; else WIDE records with d_aux in `aux_fmt`.
+static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const uint8_t* d_aux, int aux_fmt, uint64_t n) {
     PartPlan p;
     int rc = plan_alloc(h, &p, n, 0, 1);
     if (rc) return rc;
+    uint8_t* a1 = d_aux ? p.aux1 : nullptr;
+    uint8_t* a2 = d_aux ? p.aux2 : nullptr;
     hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, h->stream, p.seg_off, 0ull, (unsigned long long)n);
-    run_level(h, &p, level_flat_to_coarse(p.cfg), d_recs, p.recs1);        // group_base = coarse offsets
+    run_level(h, &p, level_flat_to_coarse(p.cfg), d_recs, d_aux, p.recs1, a1);        // group_base = coarse offsets
     if (p.two_level) {
         // the coarse offsets become the segment table of the next level
         HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)(p.cfg.n_coarse + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
-        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, p.recs2);
-        run_p3(h, &p, p.recs2, p.group_base);
+        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
+        run_p3(h, &p, p.recs2, a2, aux_fmt, p.group_base);
     } else {
-        run_p3(h, &p, p.recs1, p.group_base);
+        run_p3(h, &p, p.recs1, a1, aux_fmt, p.group_base);
     }
     HIPC(hipGetLastError());
     return KQ_OK;
@@ -1024,10 +1030,10 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
     if (rc) return rc;
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
-    bool part = h->k <= PART_MAX_K && kmers >= (1u << 20) && h->n_regions <= (1ull << 20);   // both fan-outs < NB_MAX
+    bool part = kmers >= (1u << 20) && h->n_regions <= (1ull << 20);   // both fan-outs < NB_MAX
     if (h->count_path == 1) part = false;
     if (h->count_path == 2) {
-        if (h->k > PART_MAX_K) return fail(KQ_ERR_INVALID, "partitioned count path needs k <= %d", PART_MAX_K);
+        if (h->n_regions > (1ull << 20)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
         part = true;
     }
     if (part) {
@@ -1106,30 +1112,25 @@ int kq_emit_records(kq_handle* h, const char* bases, uint64_t len, uint64_t* key
 
 int kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts, uint64_t* d_keys, uint8_t* d_edges,
                             uint64_t cap, uint64_t* part_counts) {
-    if (!h || !part_counts || n_parts < 1 || n_parts > h->map_count || (!d_bases && len)) return fail(KQ_ERR_INVALID, "bad argument");
+    if (!h || !part_counts || n_parts < 1 || n_parts > h->map_count || n_parts >= NB_MAX || (!d_bases && len))
+        return fail(KQ_ERR_INVALID, "bad argument");
     HIPC(hipSetDevice(h->device));
     for (int i = 0; i < n_parts; ++i) part_counts[i] = 0;
     if (len < (uint64_t)h->k) return KQ_OK;
+    if (cap < len - h->k + 1 || !d_keys || !d_edges) return fail(KQ_ERR_CAPACITY, "record buffer too small: need room for %llu records",
+                                                                  (unsigned long long)(len - h->k + 1));
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
-    int rc = ensure_buf(&h->scratch, &h->scratch_bytes, 2 * (size_t)n_parts * sizeof(unsigned long long));
+    PartPlan p;
+    int rc = plan_alloc(h, &p, 0, n_tiles_of(lead, len), (uint32_t)n_parts);
     if (rc) return rc;
-    unsigned long long* counts = (unsigned long long*)h->scratch;
-    unsigned long long* cursor = counts + n_parts;
-    HIPC(hipMemsetAsync(counts, 0, (size_t)n_parts * sizeof(unsigned long long), h->stream));
-    int grid = grid_for(h, n_tiles_of(lead, len), 1);
-    hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(TILE_THREADS), (size_t)n_parts * sizeof(unsigned long long), h->stream,
-                       ab, lead, len, h->k, (uint32_t)h->map_count, (uint32_t)n_parts, counts);
-    std::vector<unsigned long long> hc(n_parts), off(n_parts);
-    HIPC(hipMemcpyAsync(hc.data(), counts, (size_t)n_parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    PartCfg cfg = p.cfg;
+    cfg.mode = 1; cfg.n_coarse = (uint32_t)n_parts;
+    run_p1(h, &p, cfg, ab, lead, len, d_keys, d_edges, AUX_EDGE_BYTE);      // WIDE records: key + reference edge byte
+    std::vector<unsigned long long> off((size_t)n_parts + 1);
+    HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
-    unsigned long long run = 0;
-    for (int i = 0; i < n_parts; ++i) { off[i] = run; run += hc[i]; part_counts[i] = hc[i]; }
-    if (run > cap) return fail(KQ_ERR_CAPACITY, "record buffer too small: need %llu, have %llu", run, (unsigned long long)cap);
-    HIPC(hipMemcpyAsync(cursor, off.data(), (size_t)n_parts * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, (uint32_t)h->map_count,
-                       (uint32_t)n_parts, cursor, d_keys, d_edges, cap);
-    HIPC(hipStreamSynchronize(h->stream));   // off[] is a stack vector: keep it alive until the copy is done
+    for (int i = 0; i < n_parts; ++i) part_counts[i] = off[(size_t)i + 1] - off[(size_t)i];
     return KQ_OK;
 }
 
@@ -1150,7 +1151,7 @@ int kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_pa
     if (rc) return rc;
     PartCfg cfg = p.cfg;
     cfg.mode = 1; cfg.n_coarse = (uint32_t)n_parts;
-    run_p1(h, &p, cfg, ab, lead, len, d_recs);
+    run_p1(h, &p, cfg, ab, lead, len, d_recs, nullptr, AUX_IDX6);
     std::vector<unsigned long long> off((size_t)n_parts + 1);
     HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
@@ -1166,7 +1167,7 @@ int kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n) {
     int rc = reserve(h, n, n);
     if (rc) return rc;
     if (h->n_regions > (1ull << 20)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
-    rc = count_partitioned_records(h, d_recs, n);
+    rc = count_partitioned_records(h, d_recs, nullptr, AUX_IDX6, n);
     h->table_empty = false;
     return rc;
 }
@@ -1177,6 +1178,11 @@ int kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d
     if (!n) return KQ_OK;
     int rc = reserve(h, n, n);
     if (rc) return rc;
+    if ((h->count_path == 2 || (h->count_path == 0 && n >= (1u << 20))) && h->n_regions <= (1ull << 20)) {   // WIDE records: key + reference edge byte
+        rc = count_partitioned_records(h, d_keys, d_edges, AUX_EDGE_BYTE, n);
+        h->table_empty = false;
+        return rc;
+    }
     h->table_empty = false;
     hipLaunchKernelGGL(k_insert_records, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, h->view(), d_keys, d_edges, n);
     HIPC(hipGetLastError());

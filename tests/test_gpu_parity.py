@@ -333,11 +333,27 @@ def test_partitioned_high_copy_and_mixed_paths(kq, O):
     assert H.entries_equal(gpu.export(), cpu.export())
 
 
-def test_partitioned_rejects_large_k(kq):
-    db = kq.KreeqDB(31, 128)
-    db.set_option("count_path", "partitioned")
-    with pytest.raises(kq.KqError):
-        db.count_batch(b"ACGT" * 100)
+@pytest.mark.parametrize("k,hint", [(29, 0), (31, 5_000_000), (32, 0)])
+def test_partitioned_wide_records(kq, O, k, hint):
+    """k = 29..32: the key fills the u64, edges travel in a parallel byte array through the splits"""
+    batch, genome = H.synth_reads(25000, 150, 70000, seed=60 + k, err=0.01, n_rate=0.003)
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=hint), O.OracleDB(k, 128)
+    gpu.set_option("count_path", "partitioned")
+    half = batch.rfind(b"\n", 0, len(batch) // 2)
+    for part in (batch[:half], batch[half + 1:]):
+        gpu.count_batch(part)
+        cpu.count_batch(part, threads=8)
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(gpu.export(), cpu.export())
+    # explicit records (reference edge bytes) through the partitioned insert as well
+    keys, edges = O.emit_records(k, batch)
+    g2 = kq.KreeqDB(k, 128, capacity_hint=hint)
+    g2.set_option("count_path", "partitioned")
+    g2.insert_records(keys, edges)
+    assert H.entries_equal(g2.export(), cpu.export())
+    cg, _ = g2.lookup_sequence(genome)
+    cc, _ = cpu.validate_sequence(genome, threads=8)
+    assert np.array_equal(cg, cc)
 
 
 def _unpack_records(recs):
