@@ -544,41 +544,72 @@ __global__ __launch_bounds__(256) void k_export(TableView t, uint32_t map_count,
     }
 }
 
-// K3: evaluateSegment (src/kreeq.cpp:143-219) over a whole sequence (segments = ACGT runs)
+// K3: evaluateSegment (src/kreeq.cpp:143-219) over a whole sequence (segments = ACGT runs).
+// One random 24-B probe per k-mer: measured at 27.7 G lookups/s this is the part's random 64-B
+// sector rate (a variant with 16 probes in flight per lane was not faster), so the kernel keeps the
+// simple one-k-mer-at-a-time form at full occupancy.  Per-base results are staged in LDS and
+// written out coalesced, and never read: a position is evaluated in exactly one map-range pass and
+// the caller zero-initialises the array (generateValidationVector, src/input.cpp:38-45), so only
+// found k-mers need a store.
+template <bool PER_BASE>
 __global__ __launch_bounds__(TILE_THREADS) void k_lookup(TableView t, const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len,
-                                                          int k, uint32_t map_count, uint32_t map_lo, uint32_t map_hi,
-                                                          uint32_t cov_cutoff, kq_dbgbase* per_base, unsigned long long* counters) {
-    uint64_t missing = 0, total = 0, edge_missing = 0;
-    scan_tiles(ab, lead, len, k, [&](uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
-        const bool is_fw = fw < rv;                                        // :145
-        const uint64_t key = is_fw ? fw : rv;
-        const uint32_t m = (uint32_t)(key % map_count);                    // :146
-        if (m < map_lo || m >= map_hi) return;                             // :150
-        kq_dbgbase b;
-        if (per_base) b = per_base[pos]; else { b.fw = b.bw = b.cov = 0; b.isFw = 0; b.pad[0] = b.pad[1] = b.pad[2] = 0; }
-        Logical L;
-        const Slot* s = table_find(t, key);                                // :153
-        if (s) {
-            L = slot_logical(t, s);                                        // :156-166 (8-bit or 32-bit tier)
-            b.cov = L.cov; b.isFw = is_fw;                                 // :168-169
+                                                          int k, uint32_t map_count, uint32_t map_mask, uint32_t map_lo, uint32_t map_hi,
+                                                          uint32_t cov_cutoff, kq_dbgbase* __restrict__ per_base,
+                                                          unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    __shared__ kq_dbgbase s_pb[PER_BASE ? TILE_STARTS : 1];
+    const int tid = threadIdx.x;
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    uint32_t missing = 0, total = 0, edge_missing = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        if (PER_BASE) {
+            kq_dbgbase z; z.fw = z.bw = z.cov = 0; z.isFw = 0; z.pad[0] = z.pad[1] = z.pad[2] = 0;
+            for (int j = tid; j < TILE_STARTS; j += TILE_THREADS) s_pb[j] = z;
+            __syncthreads();
         }
-        if (b.cov == 0) ++missing;                                         // :172
-        else if (b.cov < cov_cutoff) ++missing;                            // :174
-        else {
-            if (!s) { for (int e = 0; e < 8; ++e) L.e[e] = 0; }            // stale per_base cov, khmer default-constructed
-            bool no_left = false, no_right = false;
-            if (b.isFw) {                                                  // :178-193
-                if (next < 4) { uint32_t v = L.e[next]; if (v) b.fw = v; else no_right = true; }
-                if (prev < 4) { uint32_t v = L.e[4 + prev]; if (v) b.bw = v; else no_left = true; }
-            } else {                                                       // :194-210
-                if (prev < 4) { uint32_t v = L.e[3 - prev]; if (v) b.fw = v; else no_left = true; }
-                if (next < 4) { uint32_t v = L.e[4 + 3 - next]; if (v) b.bw = v; else no_right = true; }
+        lane_scan_core<false>(s_codes, s_inv, lo_valid, tile, k,
+                              [&](int i, bool, uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+            const bool is_fw = fw < rv;                                    // :145
+            const uint64_t key = is_fw ? fw : rv;
+            const uint32_t m = map_mask ? (uint32_t)key & map_mask : (uint32_t)(key % map_count);   // :146
+            if (m < map_lo || m >= map_hi) return;                         // :150
+            kq_dbgbase b;
+            b.fw = b.bw = b.cov = 0; b.isFw = 0; b.pad[0] = b.pad[1] = b.pad[2] = 0;
+            Logical L;
+            const Slot* s = table_find(t, key);                            // :153
+            if (s) {
+                L = slot_logical(t, s);                                    // :156-166 (8-bit or 32-bit tier)
+                b.cov = L.cov; b.isFw = is_fw;                             // :168-169
             }
-            if (no_left && no_right) ++edge_missing;                       // :211
+            if (b.cov == 0) ++missing;                                     // :172
+            else if (b.cov < cov_cutoff) ++missing;                        // :174
+            else {
+                bool no_left = false, no_right = false;
+                if (is_fw) {                                               // :178-193
+                    if (next < 4) { uint32_t v = L.e[next]; if (v) b.fw = v; else no_right = true; }
+                    if (prev < 4) { uint32_t v = L.e[4 + prev]; if (v) b.bw = v; else no_left = true; }
+                } else {                                                   // :194-210
+                    if (prev < 4) { uint32_t v = L.e[3 - prev]; if (v) b.fw = v; else no_left = true; }
+                    if (next < 4) { uint32_t v = L.e[4 + 3 - next]; if (v) b.bw = v; else no_right = true; }
+                }
+                if (no_left && no_right) ++edge_missing;                   // :211
+            }
+            ++total;                                                       // :216
+            if (PER_BASE && s) { b.pad[0] = 1; s_pb[16 * tid + i] = b; }
+        });
+        if (PER_BASE) {
+            __syncthreads();
+            const int64_t p0 = (int64_t)(tile * TILE_STARTS) - lo_valid;
+            for (int j = tid; j < TILE_STARTS; j += TILE_THREADS) {
+                kq_dbgbase b = s_pb[j];
+                if (b.pad[0]) { b.pad[0] = 0; per_base[p0 + j] = b; }
+            }
         }
-        if (per_base) per_base[pos] = b;
-        ++total;                                                           // :216
-    });
+        __syncthreads();
+    }
     uint64_t a = block_sum(missing), b = block_sum(total), c = block_sum(edge_missing);
     if (threadIdx.x == 0) {                                                // :223-225
         if (a) atomicAdd(&counters[0], (unsigned long long)a);
@@ -1274,9 +1305,12 @@ int kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uint
     if (len < (uint64_t)h->k) return KQ_OK;                                  // src/kreeq.cpp:123
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
-    hipLaunchKernelGGL(k_lookup, dim3(grid_for(h, n_tiles_of(lead, len), 1)), dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len,
-                       h->k, (uint32_t)h->map_count, (uint32_t)map_lo, (uint32_t)map_hi, cov_cutoff, d_per_base,
-                       (unsigned long long*)d_counters);
+    const uint32_t map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
+    const dim3 grid(grid_for(h, n_tiles_of(lead, len), 1));
+    if (d_per_base) hipLaunchKernelGGL(k_lookup<true>, grid, dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len, h->k, (uint32_t)h->map_count,
+                                       map_mask, (uint32_t)map_lo, (uint32_t)map_hi, cov_cutoff, d_per_base, (unsigned long long*)d_counters);
+    else hipLaunchKernelGGL(k_lookup<false>, grid, dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len, h->k, (uint32_t)h->map_count,
+                            map_mask, (uint32_t)map_lo, (uint32_t)map_hi, cov_cutoff, d_per_base, (unsigned long long*)d_counters);
     HIPC(hipGetLastError());
     return KQ_OK;
 }
