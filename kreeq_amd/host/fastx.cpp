@@ -1,8 +1,17 @@
 #include "fastx.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 namespace kqhost {
 
@@ -94,6 +103,159 @@ void read_batches(const std::string& path, size_t batch_bytes, const std::functi
         if (batch.size() >= batch_bytes) { on_batch(batch); batch.clear(); }
     });
     if (!batch.empty()) on_batch(batch);
+}
+
+namespace {
+
+class BatchQueue {                       // bounded multi-producer / single-consumer queue
+    std::mutex m_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<std::string> q_;
+    size_t cap_;
+    unsigned producers_;
+    std::string error_;
+public:
+    BatchQueue(size_t cap, unsigned producers) : cap_(cap), producers_(producers) {}
+    void push(std::string&& b) {
+        std::unique_lock<std::mutex> l(m_);
+        not_full_.wait(l, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(b));
+        not_empty_.notify_one();
+    }
+    void producer_done(const std::string& err = std::string()) {
+        std::lock_guard<std::mutex> l(m_);
+        if (!err.empty() && error_.empty()) error_ = err;
+        --producers_;
+        not_empty_.notify_all();
+    }
+    bool pop(std::string& out) {         // false when all producers are done and the queue is empty
+        std::unique_lock<std::mutex> l(m_);
+        not_empty_.wait(l, [&] { return !q_.empty() || producers_ == 0; });
+        if (q_.empty()) { if (!error_.empty()) throw std::runtime_error(error_); return false; }
+        out = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+};
+
+inline const char* next_line(const char* p, const char* end) {
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+    return nl ? nl + 1 : end;
+}
+// first FASTQ record starting at or after `p`: a line starting with '@' whose line + 2 starts with '+'
+// (a quality line may start with '@', but then line + 2 is a sequence line)
+const char* fastq_sync(const char* p, const char* begin, const char* end) {
+    if (p != begin) p = next_line(p - 1, end);          // start of the line after the one containing p-1
+    while (p < end) {
+        if (*p == '@') {
+            const char* l1 = next_line(p, end);
+            const char* l2 = next_line(l1, end);
+            if (l2 < end && *l2 == '+') return p;
+            if (l2 >= end) return p;                     // truncated tail: let the parser deal with it
+        }
+        p = next_line(p, end);
+    }
+    return end;
+}
+const char* fasta_sync(const char* p, const char* begin, const char* end) {
+    if (p != begin) p = next_line(p - 1, end);
+    while (p < end && *p != '>') p = next_line(p, end);
+    return p;
+}
+
+void append_seq(std::string& batch, const char* a, const char* b) {
+    while (b > a && (b[-1] == '\n' || b[-1] == '\r')) --b;
+    if (!batch.empty()) batch.push_back('\n');
+    batch.append(a, (size_t)(b - a));
+}
+
+}  // namespace
+
+void read_batches_parallel(const std::string& path, size_t batch_bytes, unsigned threads,
+                           const std::function<void(const std::string&)>& on_batch) {
+    if (threads < 1) threads = 1;
+    struct stat st;
+    const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    int fd = -1;
+    const char* data = nullptr;
+    size_t size = 0;
+    if (!gz && stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd >= 0) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { data = (const char*)m; size = (size_t)st.st_size; madvise(m, size, MADV_SEQUENTIAL); }
+        }
+    }
+    if (!data || (data[0] != '@' && data[0] != '>')) {
+        // compressed / piped / unknown: one producer thread runs the sequential reader
+        if (data) { munmap((void*)data, size); }
+        if (fd >= 0) close(fd);
+        BatchQueue q(4, 1);
+        std::thread prod([&] {
+            try { read_batches(path, batch_bytes, [&](const std::string& b) { q.push(std::string(b)); }); q.producer_done(); }
+            catch (const std::exception& e) { q.producer_done(e.what()); }
+        });
+        std::string b;
+        try { while (q.pop(b)) on_batch(b); } catch (...) { prod.join(); throw; }
+        prod.join();
+        return;
+    }
+    const bool fastq = data[0] == '@';
+    const char* begin = data;
+    const char* end = data + size;
+    const size_t chunk = std::max<size_t>((size_t)8 << 20, std::min<size_t>((size_t)64 << 20, size / (threads * 4) + 1));
+    const size_t n_chunks = (size + chunk - 1) / chunk;
+    std::mutex next_m;
+    size_t next_chunk = 0;
+    BatchQueue q(threads + 2, threads);
+    auto worker = [&] {
+        try {
+            std::string batch;
+            batch.reserve(batch_bytes + (1 << 16));
+            for (;;) {
+                size_t c;
+                { std::lock_guard<std::mutex> l(next_m); c = next_chunk++; }
+                if (c >= n_chunks) break;
+                const char* lo = begin + c * chunk;
+                const char* hi = std::min(end, lo + chunk);
+                const char* p = fastq ? fastq_sync(lo, begin, end) : fasta_sync(lo, begin, end);
+                while (p < hi) {                          // records whose header starts inside [lo, hi)
+                    if (fastq) {
+                        const char* seq = next_line(p, end);
+                        const char* plus = next_line(seq, end);
+                        const char* qual = next_line(plus, end);
+                        append_seq(batch, seq, plus);
+                        p = next_line(qual, end);
+                    } else {
+                        const char* seq = next_line(p, end);
+                        const char* nxt = seq;
+                        while (nxt < end && *nxt != '>') nxt = next_line(nxt, end);
+                        if (!batch.empty()) batch.push_back('\n');
+                        for (const char* s = seq; s < nxt;) {           // drop the line breaks (src/input.cpp:225)
+                            const char* e = next_line(s, nxt);
+                            const char* t = e;
+                            while (t > s && (t[-1] == '\n' || t[-1] == '\r')) --t;
+                            batch.append(s, (size_t)(t - s));
+                            s = e;
+                        }
+                        p = nxt;
+                    }
+                    if (batch.size() >= batch_bytes) { q.push(std::move(batch)); batch.clear(); batch.reserve(batch_bytes + (1 << 16)); }
+                }
+            }
+            if (!batch.empty()) q.push(std::move(batch));
+            q.producer_done();
+        } catch (const std::exception& e) { q.producer_done(e.what()); }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker);
+    std::string b;
+    try { while (q.pop(b)) on_batch(b); }
+    catch (...) { for (auto& t : pool) t.detach(); munmap((void*)data, size); close(fd); throw; }
+    for (auto& t : pool) t.join();
+    munmap((void*)data, size);
+    close(fd);
 }
 
 }  // namespace kqhost

@@ -19,4 +19,13 @@ void read_fastx(const std::string& path, const std::function<void(SeqRecord&&)>&
 // k-mers never span two reads), at most ~batch_bytes each.
 void read_batches(const std::string& path, size_t batch_bytes, const std::function<void(const std::string&)>& on_batch);
 
+// Same contract, but the file is parsed by `threads` workers and handed to on_batch (called on the
+// CALLING thread only) through a bounded queue, so parsing overlaps the GPU work done inside
+// on_batch.  Plain FASTQ/FASTA files are mmap'ed and cut into chunks at record boundaries; .gz
+// input is inflated by one producer thread.  Batch order is unspecified (counting is commutative).
+// Replaces gfalibs loadKmers' reader thread + readBatches queue (reference src/input.cpp:95-96,
+// src/graph-builder.cpp:41-58).
+void read_batches_parallel(const std::string& path, size_t batch_bytes, unsigned threads,
+                           const std::function<void(const std::string&)>& on_batch);
+
 }  // namespace kqhost

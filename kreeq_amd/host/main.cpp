@@ -15,6 +15,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fastx.h"
@@ -246,7 +247,8 @@ int run(UserInput& ui) {
                 e.create(std::min<uint64_t>(bytes / 2 + (1 << 20), 1ull << 31));
                 verbose("Loading input reads.");
                 for (auto& f : ui.inReads)
-                    read_batches(f, (size_t)256 << 20, [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
+                    read_batches_parallel(f, (size_t)128 << 20, ui.maxThreads > 0 ? (unsigned)ui.maxThreads : std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
+                                          [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
                 verbose("Reads loaded.");
             } else {                                                 // Input::loadGraph, src/input.cpp:56-74
                 if (ui.kmerDB.size() > 1) die("More than one DBG database provided. Merge them first. Exiting.");
@@ -318,8 +320,27 @@ int main(int argc, char** argv) {
                 write_db(argv[4], idx.k, idx.map_count, entries);
                 return EXIT_SUCCESS;
             }
+            if (argc >= 4 && std::string(argv[2]) == "seqsum") {       // order-independent digest of the sequences a reader yields
+                const unsigned threads = argc > 4 ? (unsigned)atoi(argv[4]) : 0;
+                const size_t batch = argc > 5 ? (size_t)atoll(argv[5]) : ((size_t)1 << 20);
+                unsigned long long n = 0, bases = 0, digest = 0;
+                auto eat = [&](const std::string& b) {
+                    size_t i = 0;
+                    while (i <= b.size()) {
+                        size_t j = b.find('\n', i);
+                        if (j == std::string::npos) j = b.size();
+                        unsigned long long hsh = 1469598103934665603ull;
+                        for (size_t c = i; c < j; ++c) { hsh ^= (unsigned char)b[c]; hsh *= 1099511628211ull; }
+                        ++n; bases += j - i; digest += hsh;
+                        i = j + 1;
+                    }
+                };
+                if (threads == 0) read_batches(argv[3], batch, eat); else read_batches_parallel(argv[3], batch, threads, eat);
+                printf("%llu %llu %llu\n", n, bases, digest);
+                return EXIT_SUCCESS;
+            }
         } catch (const std::exception& ex) { fprintf(stderr, "%s\n", ex.what()); return EXIT_FAILURE; }
-        fprintf(stderr, "usage: kreeq dbtool dump <db.kreeq> | rewrite <in.kreeq> <out.kreeq>\n");
+        fprintf(stderr, "usage: kreeq dbtool dump <db.kreeq> | rewrite <in.kreeq> <out.kreeq> | seqsum <fastx> [threads] [batch_bytes]\n");
         return EXIT_FAILURE;
     }
     if (mode == "validate") ui.mode = 0;
@@ -383,7 +404,7 @@ int main(int argc, char** argv) {
                     printf("\t\t .kreeq dumps hashmaps to file for reuse; .kwig .bkwig per-base tables; .hist coverage histogram.\n");
                     printf("\t-t --tmp-prefix prefix to temporary directory (unused: the table lives in HBM).\n");
                     printf("\t-m --max-memory accepted for compatibility.\n");
-                    printf("\t-j --threads <n> accepted for compatibility.\n");
+                    printf("\t-j --threads <n> parser threads for the read files (default: up to 16).\n");
                     printf("\t--device <n> GPU to use (default 0).\n");
                     printf("\t-v --version software version.\n");
                     printf("\t--cmd print $0 to stdout.\n");

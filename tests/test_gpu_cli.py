@@ -90,3 +90,39 @@ def test_cli_errors(cli):
     assert p.returncode != 0
     p = subprocess.run([cli, "bogus", "-h"], capture_output=True, text=True)
     assert p.returncode != 0 and "does not exist" in p.stderr
+
+
+def test_cli_config1_end_to_end(cli, tmp_path):
+    """BASELINE configs[1] through the CLI: FASTQ file -> parallel ingest -> GPU count -> .kreeq on disk,
+    then validate the error-free genome from that database.  Checks the closed-form totals."""
+    import time
+
+    import numpy as np
+
+    from kreeq_amd import synth
+
+    n, ln, k = 1_000_000, 150, 21
+    genome = synth.genome_codes(5_000_000, seed=1)
+    reads = synth.reads_batch(genome, n, ln, seed=2, err=0.005).reshape(-1)
+    rec = np.empty((n, 3 + ln + 3 + ln + 1), dtype=np.uint8)
+    rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+    rec[:, 3:3 + ln] = np.concatenate([reads, [10]]).reshape(n, ln + 1)[:, :ln]
+    rec[:, 3 + ln:6 + ln] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 6 + ln:6 + 2 * ln] = ord("I")
+    rec[:, -1] = 10
+    fq = str(tmp_path / "reads.fastq")
+    rec.tofile(fq)
+    fa = str(tmp_path / "genome.fasta")
+    with open(fa, "wb") as f:
+        f.write(b">chr1\n" + synth.codes_to_ascii(genome).tobytes() + b"\n")
+    db = str(tmp_path / "reads.kreeq")
+    t0 = time.perf_counter()
+    out = run(cli, ["validate", "-r", fq, "-o", db])
+    dt = time.perf_counter() - t0
+    print(f"\nCLI end to end (310 MB FASTQ -> .kreeq): {dt:.2f} s = {n * (ln - k + 1) / dt / 1e6:.0f} M k-mers/s")
+    assert out[:4] == ["DBG Summary statistics:", f"Total kmers: {n * (ln - k + 1)}", out[2], "Distinct kmers: 17733815"]
+    out2 = run(cli, ["validate", "-f", fa, "-d", db])
+    assert out2[:6] == out[:6]
+    assert out2[6] == "Missing\tTotal\tQV\tError\tk\tMethod"
+    missing, total = out2[7].split("\t")[:2]
+    assert int(total) == 5_000_000 - k + 1 and int(missing) < 2000
