@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kreeq_amd.h"
@@ -791,6 +792,30 @@ static int stage_in(kq_handle* h, const void* host, size_t bytes, void** dev) {
     return KQ_OK;
 }
 
+// sort by key with a few host threads: chunk sorts, then pairwise merges
+static void parallel_sort_entries(kq_entry* a, uint64_t n) {
+    auto less = [](const kq_entry& x, const kq_entry& y) { return x.key < y.key; };
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned t = std::max(1u, std::min(16u, hw ? hw : 1u));
+    while (t > 1 && n / t < (1u << 16)) t /= 2;
+    if (t <= 1) { std::sort(a, a + n, less); return; }
+    std::vector<uint64_t> cut(t + 1);
+    for (unsigned i = 0; i <= t; ++i) cut[i] = n * i / t;
+    {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < t; ++i) th.emplace_back([&, i] { std::sort(a + cut[i], a + cut[i + 1], less); });
+        for (auto& x : th) x.join();
+    }
+    for (unsigned width = 1; width < t; width *= 2) {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i + width < t; i += 2 * width) {
+            const uint64_t lo = cut[i], mid = cut[i + width], hi = cut[std::min(i + 2 * width, t)];
+            th.emplace_back([=] { std::inplace_merge(a + lo, a + mid, a + hi, less); });
+        }
+        for (auto& x : th) x.join();
+    }
+}
+
 extern "C" {
 
 const char* kq_last_error(void) { return g_err.c_str(); }
@@ -1413,7 +1438,7 @@ int kq_export(kq_handle* h, uint16_t map_lo, uint16_t map_hi, kq_entry* out, uin
         else if (n) {
             e = hipMemcpy(out, d_out, n * sizeof(kq_entry), hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = fail(KQ_ERR_HIP, "export copy failed: %s", hipGetErrorString(e));
-            else std::sort(out, out + n, [](const kq_entry& a, const kq_entry& b) { return a.key < b.key; });
+            else parallel_sort_entries(out, n);
         }
     }
     hipFree(d_n);

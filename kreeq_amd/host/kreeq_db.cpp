@@ -3,10 +3,13 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 namespace kqhost {
 
@@ -197,7 +200,24 @@ void write_db(const std::string& db, int k, int map_count, const std::vector<kq_
         }
         maps[m].emplace_back(e.key, v8);
     }
-    for (int m = 0; m < map_count; ++m) write_dump<Val8>(db + "/.map." + std::to_string(m) + ".bin", maps[(size_t)m]);
+    // one file per map: independent, so write them with a few threads
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
+        std::atomic<int> next{0};
+        std::mutex err_m;
+        std::string err;
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&] {
+                for (int m; (m = next.fetch_add(1)) < map_count;) {
+                    try { write_dump<Val8>(db + "/.map." + std::to_string(m) + ".bin", maps[(size_t)m]); }
+                    catch (const std::exception& e) { std::lock_guard<std::mutex> l(err_m); if (err.empty()) err = e.what(); }
+                }
+            });
+        for (auto& t : pool) t.join();
+        if (!err.empty()) throw std::runtime_error(err);
+    }
     write_dump<Val32>(db + "/.map.hc.bin", hc);
     write_index(db, k, map_count);
 }

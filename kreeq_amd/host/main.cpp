@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,7 +42,9 @@ struct UserInput {                       // reference UserInputKreeq (include/in
 
 int verbose_flag = 0, cmd_flag = 0;
 
-void verbose(const std::string& s) { if (verbose_flag) std::cerr << s << std::endl; }
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+const double t_start = now_s();
+void verbose(const std::string& s) { if (verbose_flag) fprintf(stderr, "[%8.3f s] %s\n", now_s() - t_start, s.c_str()); }
 
 [[noreturn]] void die(const std::string& msg) {
     fprintf(stderr, "%s\n", msg.c_str());
@@ -159,6 +162,7 @@ struct Engine {
         kq_or_die(kq_export(h, 0, (uint16_t)map_count, nullptr, 0, &n));
         std::vector<kq_entry> entries((size_t)n);
         if (n) kq_or_die(kq_export(h, 0, (uint16_t)map_count, entries.data(), n, &n));
+        verbose("Table exported (" + std::to_string(n) + " k-mers)");
         write_db(dir, k, map_count, entries);
     }
 
@@ -219,13 +223,13 @@ struct Engine {
     void report() {                                                  // DBG::report, src/kreeq-output.cpp:34-136
         std::string ext = "stdout";
         if (ui.outFile != "") ext = file_ext("." + ui.outFile);
-        if (ui.outFile.find(".") != std::string::npos || ui.outFile == "" || ext == "kreeq") stats();
+        if (ui.outFile.find(".") != std::string::npos || ui.outFile == "" || ext == "kreeq") { stats(); verbose("Summary computed"); }
         verbose("Writing ouput: " + ui.outFile);
         const bool per_base_out = (ext == "kwig" || ext == "bkwig");
         if (ext == "gfa" || ext == "gfa2" || ext == "gfa.gz" || ext == "gfa2.gz" || ext == "vcf")
             die("Error: ." + ext + " output (variant search) is not supported by this build");
         if (ext != "kreeq" && ext != "hist" && ui.mode == 0) validate_sequences(per_base_out);
-        if (ext == "kreeq") write_kreeq_db(ui.outFile);
+        if (ext == "kreeq") { write_kreeq_db(ui.outFile); verbose("Database written"); }
         else if (ext == "kwig") write_kwig(ui.outFile);
         else if (ext == "bkwig") write_bkwig(ui.outFile);
         else if (ext == "hist") write_hist(ui.outFile);
