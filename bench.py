@@ -59,7 +59,7 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -78,6 +78,7 @@ def main():
     engine.db.set_option("trust_capacity", 1)     # the hint is an upper bound of the distinct k-mers (jellyfish -s style)
     engine.db.set_option("count_path", args.path)
     counter = ShardedCounter(engine, K, 128, sharded_path=args.sharded)
+    counter.force_exchange = args.sharded and dist.is_initialized()      # rehearse the RCCL exchange even at world size 1
 
     def step():
         engine.clear()
@@ -138,7 +139,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(reads_np)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -43,21 +43,25 @@ class GpuEngine:
         cur = torch.cuda.current_stream(self.device)
         self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(self.device)
         self.db.set_stream(self.stream.cuda_stream)
-        self._keys = self._edges = None
+        self._send = {}
 
-    def emit_partitioned(self, bases: torch.Tensor, n_parts: int):
-        """-> ([payload tensors grouped by owner part], per-part record counts)"""
+    def emit_partitioned(self, bases: torch.Tensor, n_parts: int, slot: int = 0):
+        """-> ([payload tensors grouped by owner part], per-part record counts).  `slot` selects one of
+        two send buffers, so a chunk can be scanned while the previous one is still being exchanged."""
         n = bases.numel()
-        if self._keys is None or self._keys.numel() < n:
-            self._keys = torch.empty(n, dtype=torch.int64, device=self.device)
-            self._edges = torch.empty(n, dtype=torch.uint8, device=self.device) if self.k > 28 else None
+        buf = self._send.get(slot)
+        if buf is None or buf[0].numel() < n:
+            buf = (torch.empty(n, dtype=torch.int64, device=self.device),
+                   torch.empty(n, dtype=torch.uint8, device=self.device) if self.k > 28 else None)
+            self._send[slot] = buf
+        keys, edges = buf
         if self.k <= 28:        # packed 8-byte records: one array to exchange, atomic-free receive side
-            counts = self.db.emit_packed_dev(bases.data_ptr(), n, n_parts, self._keys.data_ptr(), n)
+            counts = self.db.emit_packed_dev(bases.data_ptr(), n, n_parts, keys.data_ptr(), keys.numel())
             tot = int(counts.sum())
-            return [self._keys[:tot]], counts.astype(np.int64)
-        counts = self.db.emit_partitioned_dev(bases.data_ptr(), n, n_parts, self._keys.data_ptr(), self._edges.data_ptr(), n)
+            return [keys[:tot]], counts.astype(np.int64)
+        counts = self.db.emit_partitioned_dev(bases.data_ptr(), n, n_parts, keys.data_ptr(), edges.data_ptr(), keys.numel())
         tot = int(counts.sum())
-        return [self._keys[:tot], self._edges[:tot]], counts.astype(np.int64)
+        return [keys[:tot], edges[:tot]], counts.astype(np.int64)
 
     def count(self, bases: torch.Tensor):
         """fused K1+K2 (no record materialisation): the single-GPU path"""
@@ -91,6 +95,7 @@ class ShardedCounter:
         self.engine, self.k, self.map_count, self.group = engine, k, map_count, group
         self.sharded_path = sharded_path
         self.force_exchange = False
+        self.n_chunks = 4                      # pipeline depth of the exchange
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if self.world > map_count:
@@ -108,27 +113,67 @@ class ShardedCounter:
         with self._stream_ctx():
             return self._count_batch(bases)
 
-    def _count_batch(self, bases: torch.Tensor):
-        if self.world == 1 and hasattr(self.engine, "count") and not self.sharded_path:
-            self.engine.count(bases)
-            return None
-        payload, send_counts = self.engine.emit_partitioned(bases, self.world)
-        if self.world == 1 and not self.force_exchange:
-            self.engine.insert(payload)
-            return int(send_counts.sum())
+    def _cut_points(self, bases: torch.Tensor, n_chunks: int):
+        """chunk boundaries at read separators (a non-ACGT byte), so that no k-mer is cut"""
+        n = bases.numel()
+        cuts = [0]
+        for i in range(1, n_chunks):
+            lo = max(cuts[-1], n * i // n_chunks)
+            win = bases[lo:min(n, lo + (1 << 16))]
+            is_base = torch.zeros_like(win, dtype=torch.bool)
+            for c in b"ACGTacgt":
+                is_base |= win == c
+            sep = (~is_base).nonzero()
+            if sep.numel() == 0:
+                continue                                        # no separator nearby: make this chunk longer
+            cuts.append(lo + int(sep[0]) + 1)
+        cuts.append(n)
+        return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+
+    def _exchange_start(self, payload, send_counts):
+        """counts first (blocking, tiny), then one asynchronous all-to-all(v) per payload array"""
         dev = payload[0].device
         sc = torch.from_numpy(send_counts).to(dev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)                 # how many records each peer sends me
         recv_counts = rc.cpu().numpy()
         n_recv = int(recv_counts.sum())
-        received = []
-        for t in payload:                                                # all-to-all(v), one per payload array
+        received, works = [], []
+        for t in payload:
             r = torch.empty(n_recv, dtype=t.dtype, device=dev)
-            dist.all_to_all_single(r, t, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(), group=self.group)
+            works.append(dist.all_to_all_single(r, t, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
+                                                group=self.group, async_op=True))
             received.append(r)
-        self.engine.insert(received)
-        return n_recv
+        return received, works, n_recv
+
+    def _count_batch(self, bases: torch.Tensor):
+        if self.world == 1 and hasattr(self.engine, "count") and not self.sharded_path:
+            self.engine.count(bases)
+            return None
+        if self.world == 1 and not self.force_exchange:
+            payload, send_counts = self.engine.emit_partitioned(bases, self.world)
+            self.engine.insert(payload)
+            return int(send_counts.sum())
+        # pipeline over chunks: the all-to-all of chunk i runs while chunk i-1 is inserted and chunk
+        # i+1 is scanned (xGMI is point-to-point: the exchange costs about as much as the compute)
+        n_total, pending = 0, None
+        for i, (lo, hi) in enumerate(self._cut_points(bases, self.n_chunks)):
+            # send buffer i % 2: the exchange of chunk i-2 was waited for before chunk i-1 was started
+            payload, send_counts = self.engine.emit_partitioned(bases[lo:hi], self.world, slot=i % 2)
+            started = self._exchange_start(payload, send_counts)
+            if pending is not None:
+                received, works, _ = pending
+                for w in works:
+                    w.wait()
+                self.engine.insert(received)
+            pending = started
+            n_total += started[2]
+        if pending is not None:
+            received, works, _ = pending
+            for w in works:
+                w.wait()
+            self.engine.insert(received)
+        return n_total
 
     def validate(self, bases: torch.Tensor, cov_cutoff=0):
         """every rank passes the SAME assembly sequence; returns the global (missing, total, edgeMissing)"""

@@ -89,8 +89,26 @@ void read_fastx(const std::string& path, const std::function<void(SeqRecord&&)>&
         }
     } else if (c == -1) {
         return;
+    } else if (c == 'H' || c == 'S') {
+        // GFA: only the S-line sequences matter to validate (each segment is looked up on its own;
+        // reference src/input.cpp:287-291 -> gfalibs readGFA).  GFA2 S lines carry the length first.
+        bool gfa2 = false;
+        while (in.getline(line)) {
+            while (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.rfind("H\t", 0) == 0 && line.find("VN:Z:2") != std::string::npos) gfa2 = true;
+            if (line.rfind("S\t", 0) != 0) continue;
+            std::vector<std::string> f;
+            size_t i = 0;
+            while (i <= line.size()) { size_t j = line.find('\t', i); if (j == std::string::npos) j = line.size(); f.push_back(line.substr(i, j - i)); i = j + 1; }
+            const size_t si = gfa2 ? 3 : 2;
+            if (f.size() <= si || f[si] == "*") continue;
+            SeqRecord r;
+            r.header = f[1];
+            r.seq = f[si];
+            on_record(std::move(r));
+        }
     } else {
-        throw std::runtime_error("unsupported sequence format (FASTA/FASTQ expected): " + path);
+        throw std::runtime_error("unsupported sequence format (FASTA/FASTQ/GFA expected): " + path);
     }
 }
 

@@ -84,8 +84,6 @@ struct Assembly {
 };
 
 void load_genome(const std::string& path, Assembly& a) {          // reference Input::loadGenome, src/input.cpp:188-308
-    std::string ext = file_ext(path);
-    if (ext.rfind("gfa", 0) == 0) die("GFA input is not supported by this build (FASTA/FASTQ only): " + path);
     read_fastx(path, [&](SeqRecord&& r) { a.seqs.push_back(std::move(r)); });
     size_t total = 0;
     for (auto& s : a.seqs) total += s.seq.size() + 1;

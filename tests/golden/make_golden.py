@@ -3,7 +3,7 @@
 /root/reference does not exist on the GPU box and nothing at test time reads it).
 
 What is committed here is DATA, not reference source:
-  inputs/            the reference's test inputs (FASTA/FASTQ/.gz/.bed/.bkwig), byte for byte
+  inputs/            the reference's test inputs (FASTA/FASTQ/.gz/.gfa/.bed/.bkwig), byte for byte
   validateFiles/     the reference's golden stdout files (line 1 = command, line 2 = "embedded",
                      rest = expected stdout; harness: reference src/validate.cpp:52-122)
   kreeq_dbs.tar.gz   the 10 fixture databases testFiles/*.kreeq (phmap binary dumps), tarred
@@ -76,11 +76,11 @@ def main():
     os.makedirs(inp, exist_ok=True)
     for f in sorted(os.listdir(os.path.join(REF, "testFiles"))):
         p = os.path.join(REF, "testFiles", f)
-        if os.path.isfile(p) and f.split(".")[-1] in ("fasta", "fastq", "gz", "bed", "bkwig"):
+        if os.path.isfile(p) and f.split(".")[-1] in ("fasta", "fastq", "gz", "bed", "bkwig", "gfa"):
             shutil.copyfile(p, os.path.join(inp, f))
     vf = os.path.join(HERE, "validateFiles")
     os.makedirs(vf, exist_ok=True)
-    # validate (0-14, 20-34; 15-19 are GFA input = out of scope), union (35), bkwig (48,49), vcf (50)
+    # validate (0-34), union (35), bkwig (48,49), vcf (50)
     for i in list(range(0, 36)) + [48, 49, 50]:
         shutil.copyfile(os.path.join(REF, "validateFiles", f"test.{i}.tst"), os.path.join(vf, f"test.{i}.tst"))
     tabs = os.path.join(HERE, "db_tables")

@@ -32,8 +32,14 @@ def read_fastx(path):
             if not lines[i].startswith(b"@"):
                 break
             out.append((lines[i][1:].split(b" ")[0].decode(), lines[i + 1].strip()))
+    elif data[:1] in (b"H", b"S"):                       # GFA: the sequences of the S lines
+        gfa2 = b"VN:Z:2" in data.split(b"\n", 1)[0]
+        for line in data.split(b"\n"):
+            f = line.split(b"\t")
+            if f[0] == b"S" and len(f) >= (4 if gfa2 else 3) and f[3 if gfa2 else 2] != b"*":
+                out.append((f[1].decode(), f[3 if gfa2 else 2].strip()))
     else:
-        raise ValueError("not FASTA/FASTQ: " + path)
+        raise ValueError("not FASTA/FASTQ/GFA: " + path)
     return out
 
 

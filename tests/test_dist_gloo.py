@@ -20,7 +20,7 @@ class HostEngine:
         self.O, self.k, self.map_count = O, k, map_count
         self.db = O.OracleDB(k, map_count)
 
-    def emit_partitioned(self, bases, n_parts):
+    def emit_partitioned(self, bases, n_parts, slot=0):
         from kreeq_amd.dist import owner_of
 
         keys, edges = self.O.emit_records(self.k, bases.numpy().tobytes())
