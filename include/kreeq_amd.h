@@ -102,8 +102,10 @@ void* kq_get_stream(kq_handle* h);
  *                          distinct k-mers the table will ever hold, so batches do not pre-grow the
  *                          table for their worst case (all k-mers new).  If the bound is wrong a
  *                          table region overflows and the next sync returns KQ_ERR_TABLE_FULL.
- *   KQ_OPT_COUNT_PATH      0 = auto, 1 = direct (global atomics), 2 = partitioned (LDS regions; k <= 28) */
-enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2 };
+ *   KQ_OPT_COUNT_PATH      0 = auto, 1 = direct (global atomics), 2 = partitioned (LDS regions)
+ *   KQ_OPT_SLICE_KMERS     k-mer starts processed per internal slice of a resident batch (default 2^28;
+ *                          the partition scratch is 16 bytes per start) */
+enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3 };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_sync(kq_handle* h);
 int  kq_get_info(kq_handle* h, kq_info* out);

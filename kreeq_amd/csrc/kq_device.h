@@ -316,11 +316,18 @@ __device__ __forceinline__ void tile_lane_scan(const uint32_t* s_codes, const ui
     lane_scan_core<false>(s_codes, s_inv, lo_valid, tile, k,
                           [&](int, bool, uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) { f(pos, fw, rv, prev, next); });
 }
-// f(i, valid, fw, rv, prev, next) for all 16 starts
+// k-mer starts a launch may process, in caller positions: lets the host cut a huge batch into
+// slices that share the input array (a slice's scan window includes the neighbouring bases)
+struct EmitRange { uint64_t lo, hi; };
+
+// f(i, valid, fw, rv, prev, next) for all 16 starts; starts outside `er` are reported invalid
 template <class F>
-__device__ __forceinline__ void tile_lane_scan_all(const uint32_t* s_codes, const uint32_t* s_inv, int k, F&& f) {
-    lane_scan_core<true>(s_codes, s_inv, 0, 0, k,
-                         [&](int i, bool valid, uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) { f(i, valid, fw, rv, prev, next); });
+__device__ __forceinline__ void tile_lane_scan_all(const uint32_t* s_codes, const uint32_t* s_inv, int64_t lo_valid, uint64_t tile,
+                                                   int k, EmitRange er, F&& f) {
+    lane_scan_core<true>(s_codes, s_inv, lo_valid, tile, k,
+                         [&](int i, bool valid, uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+                             f(i, valid && pos >= er.lo && pos < er.hi, fw, rv, prev, next);
+                         });
 }
 
 // number of valid k-mer starts among this lane's 16

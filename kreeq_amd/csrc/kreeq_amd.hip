@@ -24,10 +24,11 @@ using namespace kq;
 // K1+K2 fused: hashSequences (src/graph-builder.cpp:75-113) + processBuffers (:160-206) without
 // materialising the 9-byte records: 1 B/base streamed in, random RMW on the table.
 __global__ __launch_bounds__(TILE_THREADS) void k_count_direct(TableView t, const uint8_t* __restrict__ ab,
-                                                                uint64_t lead, uint64_t len, int k) {
+                                                                uint64_t lead, uint64_t len, int k, EmitRange er) {
     uint32_t n_new = 0;
     uint64_t n_kmers = 0;
-    scan_tiles(ab, lead, len, k, [&](uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+    scan_tiles(ab, lead, len, k, [&](uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+        if (pos < er.lo || pos >= er.hi) return;
         const bool is_fw = fw < rv;
         const uint64_t key = is_fw ? fw : rv;
         uint32_t ins = 0;
@@ -125,7 +126,7 @@ __device__ __forceinline__ uint32_t p1_col(uint32_t vb, uint32_t g1) { return (v
 
 // P1 pass A: per-workgroup counts of coarse buckets -> M1[bin][column] (u64, bin-major)
 __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
-                                                          PartCfg cfg, uint32_t g1, unsigned long long* __restrict__ m1) {
+                                                          PartCfg cfg, EmitRange er, uint32_t g1, unsigned long long* __restrict__ m1) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
     __shared__ uint32_t s_hist[NB_MAX];
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
     const uint64_t n_tiles = n_tiles_of(lead, len);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);         // barrier inside (also covers the zeroing above)
-        tile_lane_scan_all(s_codes, s_inv, k, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
+        tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
             if (valid) atomicAdd(&s_hist[p1_bin(cfg, fw < rv ? fw : rv)], 1u);
         });
         __syncthreads();
@@ -154,7 +155,7 @@ __global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const un
 // P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
 template <bool WIDE>
 __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
-                                                             PartCfg cfg, const unsigned long long* __restrict__ m1,
+                                                             PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
                                                              uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __re
         if (tile + gridDim.x < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + gridDim.x);   // in flight during the split
         uint64_t rec[MS_ITEMS];
         uint32_t aux[MS_ITEMS], bin[MS_ITEMS];
-        tile_lane_scan_all(s_codes, s_inv, k, [&](int i, bool valid, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+        tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int i, bool valid, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
             const bool is_fw = fw < rv;
             const uint64_t key = is_fw ? fw : rv;
             if (WIDE) {
@@ -656,6 +657,7 @@ struct kq_handle {
     bool table_empty = true;         // nothing inserted since kq_create / kq_clear
     bool trust_capacity = false;     // KQ_OPT_TRUST_CAPACITY: capacity_hint bounds the distinct k-mers
     int count_path = 0;              // KQ_OPT_COUNT_PATH: 0 auto, 1 direct (global atomics), 2 partitioned
+    uint64_t slice_kmers = 1ull << 28;   // KQ_OPT_SLICE_KMERS
     void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
 
     TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; return v; }
@@ -909,6 +911,9 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
         case KQ_OPT_COUNT_PATH:
             if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_COUNT_PATH must be 0, 1 or 2");
             h->count_path = (int)value; return KQ_OK;
+        case KQ_OPT_SLICE_KMERS:
+            if (value < 1) return fail(KQ_ERR_INVALID, "KQ_OPT_SLICE_KMERS must be positive");
+            h->slice_kmers = (uint64_t)value; return KQ_OK;
         default: return fail(KQ_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -997,13 +1002,13 @@ static void scan_u64(kq_handle* h, unsigned long long* a, uint64_t n, unsigned l
 }
 // P1 on bases with the given bin function; afterwards p->seg_off[0..bins] are the bucket offsets
 // (seg_off[bins] = number of records) and `out` holds the records grouped by bin
-static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t* ab, uint64_t lead, uint64_t len, uint64_t* out,
+static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er, uint64_t* out,
                    uint8_t* out_aux, int aux_fmt) {
-    hipLaunchKernelGGL(k_p1_hist, dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, p->g1, p->m1);
+    hipLaunchKernelGGL(k_p1_hist, dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1);
     scan_u64(h, p->m1, (uint64_t)cfg.n_coarse * p->g1 * P1_F, p->sums, p->total);
     hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, p->m1, p->total, cfg, p->g1, p->seg_off);
-    if (out_aux) hipLaunchKernelGGL(k_p1_scatter<true>, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, p->m1, out, out_aux, aux_fmt);
-    else hipLaunchKernelGGL(k_p1_scatter<false>, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, p->m1, out, out_aux, aux_fmt);
+    if (out_aux) hipLaunchKernelGGL(k_p1_scatter<true>, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt);
+    else hipLaunchKernelGGL(k_p1_scatter<false>, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt);
 }
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
 // afterwards p->group_base[0..n_seg*nb] are the output offsets
@@ -1037,7 +1042,7 @@ static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint
 }
 
 // partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
-static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len) {
+static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er) {
     PartPlan p;
     PartCfg c0; plan_cfg(h, &c0);
     int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), c0.n_coarse);
@@ -1045,7 +1050,7 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     const bool wide = h->k > PART_MAX_K;                       // 8-byte packed records up to k = 28, key + edge byte above
     uint8_t* a1 = wide ? p.aux1 : nullptr;
     uint8_t* a2 = wide ? p.aux2 : nullptr;
-    run_p1(h, &p, p.cfg, ab, lead, len, p.recs1, a1, AUX_IDX6);
+    run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
     if (p.two_level) {
         run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
         run_p3(h, &p, p.recs2, a2, AUX_IDX6, p.group_base);
@@ -1082,25 +1087,36 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
     HIPC(hipSetDevice(h->device));
     if (len < (uint64_t)h->k) return KQ_OK;                                  // src/graph-builder.cpp:60
     const uint64_t kmers = len - h->k + 1;
-    int rc = reserve(h, kmers, kmers);
-    if (rc) return rc;
-    const uint8_t* ab; uint64_t lead;
-    aligned_view(d_bases, &ab, &lead);
-    bool part = kmers >= (1u << 20) && h->n_regions <= (1ull << 20);   // both fan-outs < NB_MAX
-    if (h->count_path == 1) part = false;
-    if (h->count_path == 2) {
-        if (h->n_regions > (1ull << 20)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
-        part = true;
-    }
-    if (part) {
-        rc = count_partitioned(h, ab, lead, len);
+    // a resident batch of any size is processed in slices of <= 2^28 k-mer starts (the partition
+    // scratch is 16 B per start); a slice scans one extra base on the left and k on the right, so
+    // k-mers and edges across a cut are seen exactly once
+    const uint64_t slice = h->slice_kmers;
+    for (uint64_t a = 0; a < kmers; a += slice) {
+        const uint64_t b = std::min(kmers, a + slice);
+        int rc = reserve(h, b - a, b - a);
+        if (rc) return rc;
+        const uint64_t sub_off = a ? a - 1 : 0;
+        const uint64_t sub_len = std::min(len, b + h->k) - sub_off;
+        const EmitRange er{a - sub_off, b - sub_off};
+        const uint8_t* ab; uint64_t lead;
+        aligned_view(d_bases + sub_off, &ab, &lead);
+        bool part = (b - a) >= (1u << 20) && h->n_regions <= (1ull << 20);   // both fan-outs < NB_MAX
+        if (h->count_path == 1) part = false;
+        if (h->count_path == 2) {
+            if (h->n_regions > (1ull << 20)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
+            part = true;
+        }
+        if (part) {
+            rc = count_partitioned(h, ab, lead, sub_len, er);
+            h->table_empty = false;
+            if (rc) return rc;
+            continue;
+        }
         h->table_empty = false;
-        return rc;
+        hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, sub_len), 1)), dim3(TILE_THREADS), 0, h->stream,
+                           h->view(), ab, lead, sub_len, h->k, er);
+        HIPC(hipGetLastError());
     }
-    h->table_empty = false;
-    hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, len), 1)), dim3(TILE_THREADS), 0, h->stream,
-                       h->view(), ab, lead, len, h->k);
-    HIPC(hipGetLastError());
     return KQ_OK;
 }
 int kq_count_batch(kq_handle* h, const char* bases, uint64_t len) {
@@ -1182,7 +1198,7 @@ int kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, int
     if (rc) return rc;
     PartCfg cfg = p.cfg;
     cfg.mode = 1; cfg.n_coarse = (uint32_t)n_parts;
-    run_p1(h, &p, cfg, ab, lead, len, d_keys, d_edges, AUX_EDGE_BYTE);      // WIDE records: key + reference edge byte
+    run_p1(h, &p, cfg, ab, lead, len, EmitRange{0, ~0ull}, d_keys, d_edges, AUX_EDGE_BYTE);      // WIDE records: key + reference edge byte
     std::vector<unsigned long long> off((size_t)n_parts + 1);
     HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
@@ -1207,7 +1223,7 @@ int kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_pa
     if (rc) return rc;
     PartCfg cfg = p.cfg;
     cfg.mode = 1; cfg.n_coarse = (uint32_t)n_parts;
-    run_p1(h, &p, cfg, ab, lead, len, d_recs, nullptr, AUX_IDX6);
+    run_p1(h, &p, cfg, ab, lead, len, EmitRange{0, ~0ull}, d_recs, nullptr, AUX_IDX6);
     std::vector<unsigned long long> off((size_t)n_parts + 1);
     HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));

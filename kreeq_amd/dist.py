@@ -12,6 +12,8 @@ all-reduced (sum).  Summary numbers are all-reduced the same way.
 The compute engine is injected (`engine`): the product uses GpuEngine (C ABI, HBM-resident
 tensors); the gloo/CPU tests drive the same routing code with a host engine of their own.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -95,7 +97,7 @@ class ShardedCounter:
         self.engine, self.k, self.map_count, self.group = engine, k, map_count, group
         self.sharded_path = sharded_path
         self.force_exchange = False
-        self.n_chunks = 4                      # pipeline depth of the exchange
+        self.n_chunks = int(os.environ.get("KQ_EXCHANGE_CHUNKS", "2"))   # pipeline depth of the exchange
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if self.world > map_count:

@@ -453,3 +453,26 @@ def test_sharded_counter_rccl_world1(kq, O):
         assert ctr.tolist() == cc.tolist()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("path,k", [("partitioned", 21), ("direct", 21), ("partitioned", 31)])
+def test_sliced_resident_batch(kq, O, path, k):
+    """a resident batch is cut into slices at arbitrary positions (inside reads): every k-mer and
+    every edge across a cut must be counted exactly once"""
+    batch, _ = H.synth_reads(20000, 150, 60000, seed=77, err=0.01, n_rate=0.003)
+    cpu = O.OracleDB(k, 128)
+    cpu.count_batch(batch, threads=8)
+    for slice_kmers in (7, 1000, 123457, len(batch)):
+        if slice_kmers < 1000 and path == "partitioned":
+            continue                                        # thousands of tiny partition passes: covered by the direct path
+        gpu = kq.KreeqDB(k, 128)
+        gpu.set_option("count_path", path)
+        gpu.set_option("slice_kmers", slice_kmers)
+        n = 30000 if slice_kmers == 7 else len(batch)
+        sub = batch[:n]
+        ref = cpu
+        if n != len(batch):
+            ref = O.OracleDB(k, 128)
+            ref.count_batch(sub)
+        gpu.count_batch(sub)
+        assert H.entries_equal(gpu.export(), ref.export()), slice_kmers
