@@ -1100,7 +1100,11 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
         const EmitRange er{a - sub_off, b - sub_off};
         const uint8_t* ab; uint64_t lead;
         aligned_view(d_bases + sub_off, &ab, &lead);
-        bool part = (b - a) >= (1u << 20) && h->n_regions <= (1ull << 20);   // both fan-outs < NB_MAX
+        // partitioned path streams the whole table once per slice (2 x 24 B per slot) on top of ~37 B per
+        // record; the atomic path costs ~95 ps per record whatever the table size (~480 B at the
+        // part's streaming rate): partition unless the table is more than ~200 B per record of the slice
+        bool part = (b - a) >= (1u << 20) && h->n_regions <= (1ull << 20) &&     // both fan-outs < NB_MAX
+                    (double)h->n_slots() * sizeof(Slot) <= 200.0 * (double)(b - a);
         if (h->count_path == 1) part = false;
         if (h->count_path == 2) {
             if (h->n_regions > (1ull << 20)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
