@@ -34,7 +34,7 @@ def hipcc():
 def build_lib(force=False, verbose=False):
     if force or _stale(LIB, HIP_DEPS):
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-value",
+        cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wextra",
                "-o", LIB] + HIP_SOURCES
         if verbose:
             print(" ".join(cmd))

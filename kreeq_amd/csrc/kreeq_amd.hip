@@ -9,6 +9,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/kreeq_amd.h"
@@ -328,14 +329,24 @@ __global__ __launch_bounds__(1024) void k_scan_apply(unsigned long long* __restr
 // image is streamed back.  Global atomics only for the rare high-copy tier and the two totals.
 constexpr int P3_THREADS = 512;
 template <bool WIDE>
-__global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
+__global__ __launch_bounds__(P3_THREADS, 6) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
                                                               int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty) {
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
     __shared__ unsigned long long s_new, s_kmers;
+    // high-copy tier of this region, aggregated in LDS: a repeat k-mer with millions of instances
+    // would otherwise serialise millions of global atomics on one side-table entry
+    constexpr int HC_LDS = 64;
+    __shared__ uint64_t s_hckey[HC_LDS];
+    __shared__ uint32_t s_hccnt[HC_LDS][8];
     const int tid = threadIdx.x;
     for (uint64_t r = blockIdx.x; r < t.n_regions; r += gridDim.x) {
         const uint64_t lo = region_base[r], hi = region_base[r + 1];
         if (lo == hi) continue;                                         // block-uniform
+        if (tid < HC_LDS) {
+            s_hckey[tid] = EMPTY_KEY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_hccnt[tid][e] = 0;
+        }
         uint4* gimg = reinterpret_cast<uint4*>(t.slots + (r << REGION_SHIFT));
         uint4* limg = reinterpret_cast<uint4*>(s_img);
         if (table_is_empty) {            // first batch after kq_create / kq_clear: the image is known, skip the 48 KiB read
@@ -346,10 +357,8 @@ __global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const
         if (tid == 0) { s_new = 0; s_kmers = 0; }
         __syncthreads();
         uint32_t n_new = 0, n_ok = 0;
-        for (uint64_t i = lo + tid; i < hi; i += P3_THREADS) {
-            const uint64_t rec = recs[i];
-            const uint64_t key = WIDE ? rec : rec_key(rec);
-            const uint64_t pack = WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(recs_aux[i]) : edge_byte_to_pack(recs_aux[i])) : rec_edge_pack(rec);
+        // apply `cnt` instances of `key` with edge counts e[0..7] (each <= cnt)
+        auto apply = [&](uint64_t key, const uint32_t (&e)[8], uint32_t cnt) {
             const uint32_t off = (uint32_t)table_hash(key) & (REGION_SLOTS - 1);
             uint64_t* slot = nullptr;
             for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
@@ -361,22 +370,123 @@ __global__ __launch_bounds__(P3_THREADS) void k_count_regions(TableView t, const
                 }
                 if (cur == key) { slot = s; break; }
             }
-            if (!slot) { atomicOr(&t.st->err_table_full, 1u); continue; }
-            ++n_ok;
-            const uint64_t old = atomicAdd((unsigned long long*)&slot[2], 1ull);
-            if (old + 1 <= LOW_TIER_MAX) {
-                if (pack) atomicAdd((unsigned long long*)&slot[1], (unsigned long long)pack);
-            } else if (pack) {
-                HcSlot* hs = hc_upsert(t, key);
-                if (!hs) { atomicOr(&t.st->err_hc_full, 1u); continue; }
+            if (!slot) { atomicOr(&t.st->err_table_full, 1u); return; }
+            n_ok += cnt;
+            const uint64_t old = atomicAdd((unsigned long long*)&slot[2], (unsigned long long)cnt);
+            uint32_t any = 0;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if ((pack >> (8 * e)) & 1) atomicAdd((unsigned long long*)&hs->cnt[e], 1ull);
+            for (int w = 0; w < 8; ++w) any |= e[w];
+            if (!any) return;
+            if (old + cnt <= LOW_TIER_MAX) {                        // every e[w] <= cnt <= 254: fits the u8 lanes
+                uint64_t pack = 0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) pack |= (uint64_t)e[w] << (8 * w);
+                atomicAdd((unsigned long long*)&slot[1], (unsigned long long)pack);
+                return;
             }
+            int hslot = -1;
+            uint32_t hp = (uint32_t)(table_hash(key) >> 40) & (HC_LDS - 1);
+            for (int probe = 0; probe < HC_LDS; ++probe, hp = (hp + 1) & (HC_LDS - 1)) {
+                uint64_t cur = *(volatile uint64_t*)&s_hckey[hp];
+                if (cur == EMPTY_KEY) cur = atomicCAS((unsigned long long*)&s_hckey[hp], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                if (cur == EMPTY_KEY || cur == key) { hslot = (int)hp; break; }
+            }
+            if (hslot >= 0) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd(&s_hccnt[hslot][w], e[w]);
+            } else {                                                // more than 64 high-copy k-mers in one region: go global
+                HcSlot* hs = hc_upsert(t, key);
+                if (!hs) { atomicOr(&t.st->err_hc_full, 1u); return; }
+#pragma unroll
+                for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd((unsigned long long*)&hs->cnt[w], (unsigned long long)e[w]);
+            }
+        };
+        // Hot k-mers (repeats, homopolymers) put most lanes of a wave on ONE slot, batch after batch.
+        // Lanes that share the first active lane's key are folded into a per-wave accumulator kept in
+        // registers (wave-uniform); it is flushed to LDS only when the hot key changes.
+        auto run = [&](auto fold_tag) {
+        constexpr bool FOLD = decltype(fold_tag)::value;
+        bool have_acc = false;
+        uint64_t acc_key = 0;
+        uint32_t acc_cnt = 0, acc_e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // records are prefetched two iterations ahead (6 waves per SIMD = three 48 KiB images per CU need <= 80 VGPRs): a skewed region is walked by ONE workgroup,
+        // which must not pay a global-load latency per iteration
+        constexpr int PF = 2;
+        uint64_t pf_rec[PF];
+        uint32_t pf_aux[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const uint64_t j = lo + (uint64_t)q * P3_THREADS + tid;
+            pf_rec[q] = j < hi ? recs[j] : 0ull;
+            pf_aux[q] = (WIDE && j < hi) ? recs_aux[j] : 0u;
         }
+        for (uint64_t base = lo; base < hi; base += (uint64_t)PF * P3_THREADS) {   // wave-uniform trip count
+#pragma unroll
+          for (int q = 0; q < PF; ++q) {
+            const uint64_t i = base + (uint64_t)q * P3_THREADS + tid;
+            bool active = i < hi;
+            const uint64_t rec = pf_rec[q];
+            const uint32_t aux = pf_aux[q];
+            {
+                const uint64_t j = i + (uint64_t)PF * P3_THREADS;
+                pf_rec[q] = j < hi ? recs[j] : 0ull;
+                pf_aux[q] = (WIDE && j < hi) ? recs_aux[j] : 0u;
+            }
+            uint64_t key = 0, pack = 0;
+            if (active) {
+                key = WIDE ? rec : rec_key(rec);
+                pack = WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
+            }
+            const uint64_t act = FOLD ? __ballot(active) : 0ull;
+            if (FOLD && act) {
+                const int lead = __ffsll((unsigned long long)act) - 1;
+                const uint64_t lead_key = __shfl(key, lead, 64);
+                const bool in_grp = active && key == lead_key;
+                const uint64_t grp = __ballot(in_grp);
+                if (__popcll(grp) >= 8) {
+                    uint64_t sum = in_grp ? pack : 0ull;            // byte lanes <= 64: no carries
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                    if (have_acc && acc_key != lead_key) {
+                        if ((tid & 63) == 0) apply(acc_key, acc_e, acc_cnt);
+                        have_acc = false;
+                    }
+                    if (!have_acc) {
+                        have_acc = true; acc_key = lead_key; acc_cnt = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) acc_e[w] = 0;
+                    }
+                    acc_cnt += (uint32_t)__popcll(grp);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) acc_e[w] += (uint32_t)(sum >> (8 * w)) & 0xFFu;
+                    if (in_grp) active = false;
+                }
+            }
+            if (active) {
+                uint32_t e1[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) e1[w] = (uint32_t)(pack >> (8 * w)) & 1u;
+                apply(key, e1, 1u);
+            }
+          }
+        }
+        if (have_acc && (tid & 63) == 0) apply(acc_key, acc_e, acc_cnt);
+        };
+        // folding costs a ballot + shuffle per iteration: only regions that receive far more records than
+        // they have slots (skew, or very deep coverage) take that path
+        if (hi - lo > 32ull * REGION_SLOTS) run(std::true_type{}); else run(std::false_type{});
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { n_new += __shfl_down(n_new, o, 64); n_ok += __shfl_down(n_ok, o, 64); }
         if ((tid & 63) == 0) { if (n_new) atomicAdd(&s_new, (unsigned long long)n_new); if (n_ok) atomicAdd(&s_kmers, (unsigned long long)n_ok); }
         __syncthreads();
+        if (tid < HC_LDS && s_hckey[tid] != EMPTY_KEY) {            // flush the region's high-copy sums: one entry per k-mer
+            HcSlot* hs = hc_upsert(t, s_hckey[tid]);
+            if (!hs) atomicOr(&t.st->err_hc_full, 1u);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (s_hccnt[tid][e]) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)s_hccnt[tid][e]);
+            }
+        }
         for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) gimg[i] = limg[i];
         if (tid == 0) {
             if (s_new) atomicAdd(&t.st->slots_used, s_new);
@@ -855,7 +965,7 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
         if (hipMalloc((void**)&h->st, sizeof(DevState)) != hipSuccess || hipHostMalloc((void**)&h->st_host, sizeof(DevState)) != hipSuccess) {
             rc = fail(KQ_ERR_NOMEM, "state allocation failed"); break;
         }
-        hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream);
+        (void)hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream);
         uint64_t slots = (uint64_t)((double)(capacity_hint ? capacity_hint : (1u << 20)) / 0.7);   // load <= 0.7 at the hinted size
         uint64_t regions = (slots + REGION_SLOTS - 1) >> REGION_SHIFT;
         if (regions < 16) regions = 16;
@@ -873,16 +983,16 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
 
 void kq_destroy(kq_handle* h) {
     if (!h) return;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    if (h->slots) hipFree(h->slots);
-    if (h->hc) hipFree(h->hc);
-    if (h->st) hipFree(h->st);
-    if (h->st_host) hipHostFree(h->st_host);
-    if (h->scratch) hipFree(h->scratch);
-    if (h->stage) hipFree(h->stage);
-    if (h->part) hipFree(h->part);
-    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->slots) (void)hipFree(h->slots);
+    if (h->hc) (void)hipFree(h->hc);
+    if (h->st) (void)hipFree(h->st);
+    if (h->st_host) (void)hipHostFree(h->st_host);
+    if (h->scratch) (void)hipFree(h->scratch);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->part) (void)hipFree(h->part);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -1019,7 +1129,7 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     if (wide) hipLaunchKernelGGL(k_lv_hist<true>, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     else hipLaunchKernelGGL(k_lv_hist<false>, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
-    hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);
+    (void)hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
     scan_u64(h, p->group_base, groups + 1, p->sums, p->total + 1);
     if (wide) hipLaunchKernelGGL(k_lv_scatter<true>, dim3(h->n_cu * 2), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, p->unit_base,
                                  p->m2, p->group_base, out, out_aux);
@@ -1173,7 +1283,7 @@ int kq_emit_records(kq_handle* h, const char* bases, uint64_t len, uint64_t* key
     uint64_t* dk = nullptr; uint8_t* de = nullptr;
     if (n) {
         HIPC(hipMalloc((void**)&dk, n * sizeof(uint64_t)));
-        if (hipMalloc((void**)&de, n) != hipSuccess) { hipFree(dk); return fail(KQ_ERR_NOMEM, "record buffer allocation failed"); }
+        if (hipMalloc((void**)&de, n) != hipSuccess) { (void)hipFree(dk); return fail(KQ_ERR_NOMEM, "record buffer allocation failed"); }
         rc = emit_ordered(h, (const char*)d, len, dk, de, n, n_out);
         if (!rc) {
             hipError_t e1 = hipMemcpyAsync(keys, dk, n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream);
@@ -1181,7 +1291,7 @@ int kq_emit_records(kq_handle* h, const char* bases, uint64_t len, uint64_t* key
             hipError_t e3 = hipStreamSynchronize(h->stream);
             if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(KQ_ERR_HIP, "copying records back failed");
         }
-        hipFree(dk); hipFree(de);
+        (void)hipFree(dk); (void)hipFree(de);
     }
     return rc;
 }
@@ -1371,10 +1481,10 @@ int kq_lookup_sequence(kq_handle* h, const char* bases, uint64_t len, uint32_t c
     unsigned long long* d_ctr = nullptr;
     kq_dbgbase* d_pb = nullptr;
     HIPC(hipMalloc((void**)&d_ctr, 3 * sizeof(unsigned long long)));
-    hipMemsetAsync(d_ctr, 0, 3 * sizeof(unsigned long long), h->stream);
+    (void)hipMemsetAsync(d_ctr, 0, 3 * sizeof(unsigned long long), h->stream);
     if (per_base && len) {
-        if (hipMalloc((void**)&d_pb, len * sizeof(kq_dbgbase)) != hipSuccess) { hipFree(d_ctr); return fail(KQ_ERR_NOMEM, "per-base buffer allocation failed"); }
-        hipMemcpyAsync(d_pb, per_base, len * sizeof(kq_dbgbase), hipMemcpyHostToDevice, h->stream);
+        if (hipMalloc((void**)&d_pb, len * sizeof(kq_dbgbase)) != hipSuccess) { (void)hipFree(d_ctr); return fail(KQ_ERR_NOMEM, "per-base buffer allocation failed"); }
+        (void)hipMemcpyAsync(d_pb, per_base, len * sizeof(kq_dbgbase), hipMemcpyHostToDevice, h->stream);
     }
     rc = kq_lookup_sequence_dev(h, (const char*)d, len, cov_cutoff, map_lo, map_hi, d_pb, (uint64_t*)d_ctr);
     unsigned long long c[3] = {0, 0, 0};
@@ -1384,8 +1494,8 @@ int kq_lookup_sequence(kq_handle* h, const char* bases, uint64_t len, uint32_t c
         hipError_t e3 = hipStreamSynchronize(h->stream);
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(KQ_ERR_HIP, "lookup failed: %s", hipGetErrorString(e3));
     }
-    hipFree(d_ctr);
-    if (d_pb) hipFree(d_pb);
+    (void)hipFree(d_ctr);
+    if (d_pb) (void)hipFree(d_pb);
     if (!rc) for (int i = 0; i < 3; ++i) counters[i] += c[i];
     return rc;
 }
@@ -1442,9 +1552,9 @@ int kq_export(kq_handle* h, uint16_t map_lo, uint16_t map_hi, kq_entry* out, uin
     unsigned long long* d_n = nullptr;
     kq_entry* d_out = nullptr;
     HIPC(hipMalloc((void**)&d_n, sizeof(unsigned long long)));
-    hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream);
+    (void)hipMemsetAsync(d_n, 0, sizeof(unsigned long long), h->stream);
     if (out && cap) {
-        if (hipMalloc((void**)&d_out, cap * sizeof(kq_entry)) != hipSuccess) { hipFree(d_n); return fail(KQ_ERR_NOMEM, "export buffer allocation failed"); }
+        if (hipMalloc((void**)&d_out, cap * sizeof(kq_entry)) != hipSuccess) { (void)hipFree(d_n); return fail(KQ_ERR_NOMEM, "export buffer allocation failed"); }
     }
     hipLaunchKernelGGL(k_export, dim3(grid_for(h, h->n_slots(), 1024)), dim3(256), 0, h->stream, h->view(), (uint32_t)h->map_count,
                        (uint32_t)map_lo, (uint32_t)map_hi, d_out, d_out ? cap : 0, d_n);
@@ -1461,8 +1571,8 @@ int kq_export(kq_handle* h, uint16_t map_lo, uint16_t map_hi, kq_entry* out, uin
             else parallel_sort_entries(out, n);
         }
     }
-    hipFree(d_n);
-    if (d_out) hipFree(d_out);
+    (void)hipFree(d_n);
+    if (d_out) (void)hipFree(d_out);
     return rc;
 }
 

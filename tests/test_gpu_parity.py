@@ -476,3 +476,22 @@ def test_sliced_resident_batch(kq, O, path, k):
             ref.count_batch(sub)
         gpu.count_batch(sub)
         assert H.entries_equal(gpu.export(), ref.export()), slice_kmers
+
+
+@pytest.mark.parametrize("path", ["partitioned", "direct"])
+def test_trusted_capacity_overflow_fails_loudly(kq, path):
+    """KQ_OPT_TRUST_CAPACITY with a hint that is far too small: a table region fills up and the next
+    synchronising call reports KQ_ERR_TABLE_FULL instead of dropping k-mers silently"""
+    batch, _ = H.synth_reads(40000, 150, 4_000_000, seed=5, err=0.0)       # ~4 M distinct k-mers
+    db = kq.KreeqDB(21, 128, capacity_hint=20000)                            # 16 regions x 2048 slots
+    db.set_option("trust_capacity", 1)
+    db.set_option("count_path", path)
+    with pytest.raises(kq.KqError) as e:
+        db.count_batch(batch)
+        db.summary()
+    assert e.value.code == -5 and "overflow" in str(e.value)
+    # the same data without the promise grows the table instead
+    ok = kq.KreeqDB(21, 128, capacity_hint=20000)
+    ok.set_option("count_path", path)
+    ok.count_batch(batch)
+    assert ok.summary()["total"] == 40000 * 130
