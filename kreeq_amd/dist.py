@@ -159,7 +159,13 @@ class ShardedCounter:
         # pipeline over chunks: the all-to-all of chunk i runs while chunk i-1 is inserted and chunk
         # i+1 is scanned (xGMI is point-to-point: the exchange costs about as much as the compute)
         n_total, pending = 0, None
-        for i, (lo, hi) in enumerate(self._cut_points(bases, self.n_chunks)):
+        chunks = self._cut_points(bases, self.n_chunks)
+        # every rank must issue the same number of collectives: agree on the largest chunk count and
+        # pad with empty chunks
+        nc = torch.tensor([len(chunks)], dtype=torch.int64, device=bases.device)
+        dist.all_reduce(nc, op=dist.ReduceOp.MAX, group=self.group)
+        chunks += [(0, 0)] * (int(nc.item()) - len(chunks))
+        for i, (lo, hi) in enumerate(chunks):
             # send buffer i % 2: the exchange of chunk i-2 was waited for before chunk i-1 was started
             payload, send_counts = self.engine.emit_partitioned(bases[lo:hi], self.world, slot=i % 2)
             started = self._exchange_start(payload, send_counts)

@@ -59,7 +59,8 @@ def _worker(rank, world, port, k, out_dir):
         assert (sc.map_lo, sc.map_hi) == owner_range(rank, world, 128)
         # two batches per rank, different reads on every rank (seed depends on rank)
         for b in range(2):
-            batch, _ = H.synth_reads(1500, 100, 30000, seed=1000 + 10 * rank + b, err=0.01, n_rate=0.003)
+            n_reads = 1500 if rank != 1 else 3            # rank 1 brings a tiny batch: fewer chunks than its peers
+            batch, _ = H.synth_reads(n_reads, 100, 30000, seed=1000 + 10 * rank + b, err=0.01, n_rate=0.003)
             sc.count_batch(torch.frombuffer(bytearray(batch), dtype=torch.uint8))
         _, genome = H.synth_reads(10, 100, 30000, seed=1000)          # same genome (seed of rank 0, batch 0)
         ctr = sc.validate(torch.frombuffer(bytearray(genome), dtype=torch.uint8))
@@ -84,7 +85,7 @@ def test_sharded_count_matches_single(tmp_path, world, k):
     ref = O.OracleDB(k, 128)
     for rank in range(world):
         for b in range(2):
-            batch, _ = H.synth_reads(1500, 100, 30000, seed=1000 + 10 * rank + b, err=0.01, n_rate=0.003)
+            batch, _ = H.synth_reads(1500 if rank != 1 else 3, 100, 30000, seed=1000 + 10 * rank + b, err=0.01, n_rate=0.003)
             ref.count_batch(batch)
     _, genome = H.synth_reads(10, 100, 30000, seed=1000)
     parts = [np.load(os.path.join(tmp_path, f"entries_{r}.npy")) for r in range(world)]
