@@ -104,8 +104,12 @@ void* kq_get_stream(kq_handle* h);
  *                          table region overflows and the next sync returns KQ_ERR_TABLE_FULL.
  *   KQ_OPT_COUNT_PATH      0 = auto, 1 = direct (global atomics), 2 = partitioned (LDS regions)
  *   KQ_OPT_SLICE_KMERS     k-mer starts processed per internal slice of a resident batch (default 2^28;
- *                          the partition scratch is 16 bytes per start) */
-enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3 };
+ *                          the partition scratch is 16 bytes per start)
+ *   KQ_OPT_COUNT_MAP_RANGE value = lo | hi << 16: kq_count_batch(_dev) keeps only k-mers whose map index
+ *                          key % map_count lies in [lo, hi).  This is the reference's memory-bounded mode
+ *                          (process the maps in ranges, src/kreeq.cpp:59-74; README "HPC" runs + union):
+ *                          count the same reads once per range into separate databases, then union. */
+enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4 };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_sync(kq_handle* h);
 int  kq_get_info(kq_handle* h, kq_info* out);

@@ -145,8 +145,10 @@ class KreeqDB:
         _check(load().kq_sync(self._h))
 
     def set_option(self, option, value):
-        """option: 'trust_capacity' | 'count_path' ('auto'|'direct'|'partitioned') | 'slice_kmers'"""
-        opt = {"trust_capacity": 1, "count_path": 2, "slice_kmers": 3}[option]
+        """option: 'trust_capacity' | 'count_path' ('auto'|'direct'|'partitioned') | 'slice_kmers' | 'count_map_range' ((lo, hi))"""
+        opt = {"trust_capacity": 1, "count_path": 2, "slice_kmers": 3, "count_map_range": 4}[option]
+        if option == "count_map_range":
+            value = int(value[0]) | (int(value[1]) << 16)
         if option == "count_path":
             value = {"auto": 0, "direct": 1, "partitioned": 2}[value]
         _check(load().kq_set_option(self._h, opt, int(value)))

@@ -33,7 +33,8 @@ struct PartCfg {
     uint32_t n_coarse;    // bins of P1: ceil(R / 2^g_shift) < NB_MAX (mode 0) or n_parts (mode 1)
     uint32_t mode;        // 0: bin = coarse bucket of the key's table region; 1: bin = owner part (multi-GPU staging)
     uint32_t map_count;   // mode 1: gfalibs mapCount
-    uint32_t map_mask;    // mode 1: map_count - 1 when it is a power of two, else 0
+    uint32_t map_mask;    // map_count - 1 when it is a power of two, else 0
+    uint32_t filt_lo, filt_hi;   // count only k-mers whose map index key % map_count lies in [filt_lo, filt_hi)
 };
 
 // One level of the record split.  Input records are grouped in n_seg segments (seg_off[0..n_seg]);
@@ -147,7 +148,15 @@ __device__ __forceinline__ uint32_t owner_part_of(uint64_t key, uint32_t map_cou
     const uint32_t m = map_mask ? (uint32_t)key & map_mask : (uint32_t)(key % map_count);     // src/graph-builder.cpp:95
     return (uint32_t)(((uint64_t)m * n_parts) / map_count);
 }
+__device__ __forceinline__ uint32_t map_index(uint64_t key, uint32_t map_count, uint32_t map_mask) {
+    return map_mask ? (uint32_t)key & map_mask : (uint32_t)(key % map_count);                  // src/graph-builder.cpp:95
+}
+// bin of a key in P1, or cfg.n_coarse (the discard bin) when the map-range filter rejects it
 __device__ __forceinline__ uint32_t p1_bin(const PartCfg& cfg, uint64_t key) {
+    if (cfg.filt_lo != 0 || cfg.filt_hi != cfg.map_count) {
+        const uint32_t m = map_index(key, cfg.map_count, cfg.map_mask);
+        if (m < cfg.filt_lo || m >= cfg.filt_hi) return cfg.n_coarse;
+    }
     return cfg.mode == 0 ? (uint32_t)(region_id(key, cfg.n_regions) >> cfg.g_shift)
                          : owner_part_of(key, cfg.map_count, cfg.map_mask, cfg.n_coarse);
 }

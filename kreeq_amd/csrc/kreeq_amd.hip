@@ -25,13 +25,17 @@ using namespace kq;
 // K1+K2 fused: hashSequences (src/graph-builder.cpp:75-113) + processBuffers (:160-206) without
 // materialising the 9-byte records: 1 B/base streamed in, random RMW on the table.
 __global__ __launch_bounds__(TILE_THREADS) void k_count_direct(TableView t, const uint8_t* __restrict__ ab,
-                                                                uint64_t lead, uint64_t len, int k, EmitRange er) {
+                                                                uint64_t lead, uint64_t len, int k, EmitRange er, PartCfg filt) {
     uint32_t n_new = 0;
     uint64_t n_kmers = 0;
     scan_tiles(ab, lead, len, k, [&](uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
         if (pos < er.lo || pos >= er.hi) return;
         const bool is_fw = fw < rv;
         const uint64_t key = is_fw ? fw : rv;
+        if (filt.filt_lo != 0 || filt.filt_hi != filt.map_count) {
+            const uint32_t m = map_index(key, filt.map_count, filt.map_mask);
+            if (m < filt.filt_lo || m >= filt.filt_hi) return;
+        }
         uint32_t ins = 0;
         if (table_add(t, key, 1, edge_pack(is_fw, prev, next), nullptr, &ins)) ++n_kmers;
         n_new += ins;
@@ -137,7 +141,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);         // barrier inside (also covers the zeroing above)
         tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
-            if (valid) atomicAdd(&s_hist[p1_bin(cfg, fw < rv ? fw : rv)], 1u);
+            if (valid) {
+                const uint32_t b = p1_bin(cfg, fw < rv ? fw : rv);
+                if (b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
+            }
         });
         __syncthreads();
     }
@@ -768,6 +775,7 @@ struct kq_handle {
     bool trust_capacity = false;     // KQ_OPT_TRUST_CAPACITY: capacity_hint bounds the distinct k-mers
     int count_path = 0;              // KQ_OPT_COUNT_PATH: 0 auto, 1 direct (global atomics), 2 partitioned
     uint64_t slice_kmers = 1ull << 28;   // KQ_OPT_SLICE_KMERS
+    uint32_t filt_lo = 0, filt_hi = 0;   // KQ_OPT_COUNT_MAP_RANGE (set to [0, map_count) at creation)
     void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
 
     TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; return v; }
@@ -957,6 +965,7 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
     kq_handle* h = new (std::nothrow) kq_handle();
     if (!h) return fail(KQ_ERR_NOMEM, "host allocation failed");
     h->device = device; h->k = k; h->map_count = map_count; h->n_cu = prop.multiProcessorCount;
+    h->filt_hi = (uint32_t)map_count;
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(KQ_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     h->stream = h->own_stream;
@@ -1021,6 +1030,11 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
         case KQ_OPT_COUNT_PATH:
             if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_COUNT_PATH must be 0, 1 or 2");
             h->count_path = (int)value; return KQ_OK;
+        case KQ_OPT_COUNT_MAP_RANGE: {
+            const int64_t lo = value & 0xFFFF, hi = (value >> 16) & 0xFFFF;
+            if (lo >= hi || hi > h->map_count) return fail(KQ_ERR_INVALID, "map range [%lld,%lld) outside [0,%d]", (long long)lo, (long long)hi, h->map_count);
+            h->filt_lo = (uint32_t)lo; h->filt_hi = (uint32_t)hi; return KQ_OK;
+        }
         case KQ_OPT_SLICE_KMERS:
             if (value < 1) return fail(KQ_ERR_INVALID, "KQ_OPT_SLICE_KMERS must be positive");
             h->slice_kmers = (uint64_t)value; return KQ_OK;
@@ -1070,6 +1084,7 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg) {
     cfg->n_coarse = (uint32_t)((cfg->n_regions + (1ull << cfg->g_shift) - 1) >> cfg->g_shift);
     cfg->mode = 0; cfg->map_count = (uint32_t)h->map_count;
     cfg->map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
+    cfg->filt_lo = 0; cfg->filt_hi = (uint32_t)h->map_count;
 }
 // carve the scratch buffer for a batch of at most n_max records; n_tiles = 0 when the input is records
 static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins) {
@@ -1160,6 +1175,7 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     const bool wide = h->k > PART_MAX_K;                       // 8-byte packed records up to k = 28, key + edge byte above
     uint8_t* a1 = wide ? p.aux1 : nullptr;
     uint8_t* a2 = wide ? p.aux2 : nullptr;
+    p.cfg.filt_lo = h->filt_lo; p.cfg.filt_hi = h->filt_hi;      // KQ_OPT_COUNT_MAP_RANGE
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
     if (p.two_level) {
         run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
@@ -1227,8 +1243,10 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
             continue;
         }
         h->table_empty = false;
+        PartCfg filt; plan_cfg(h, &filt);
+        filt.filt_lo = h->filt_lo; filt.filt_hi = h->filt_hi;
         hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, sub_len), 1)), dim3(TILE_THREADS), 0, h->stream,
-                           h->view(), ab, lead, sub_len, h->k, er);
+                           h->view(), ab, lead, sub_len, h->k, er, filt);
         HIPC(hipGetLastError());
     }
     return KQ_OK;

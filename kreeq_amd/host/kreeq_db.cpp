@@ -181,45 +181,58 @@ void read_db(const std::string& db, std::vector<kq_entry>& out, DbIndex* idx_out
     if (n_tomb > n_hc) throw std::runtime_error("Error: int32 map missing 255 value from int8 map");   // src/kreeq.cpp:162
 }
 
-void write_db(const std::string& db, int k, int map_count, const std::vector<kq_entry>& entries) {
+// maps [map_lo, map_hi) from `entries` (which must only hold k-mers of those maps); high-copy
+// k-mers are appended to `hc_out` for the single .map.hc.bin written by write_db_finish
+void write_db_maps(const std::string& db, int map_count, int map_lo, int map_hi, const std::vector<kq_entry>& entries,
+                   std::vector<kq_entry>& hc_out) {
     ::mkdir(db.c_str(), 0777);
-    std::vector<std::vector<std::pair<uint64_t, Val8>>> maps((size_t)map_count);
-    std::vector<std::pair<uint64_t, Val32>> hc;
+    std::vector<std::vector<std::pair<uint64_t, Val8>>> maps((size_t)(map_hi - map_lo));
     for (const kq_entry& e : entries) {
-        const size_t m = (size_t)(e.key % (uint64_t)map_count);
+        const int m = (int)(e.key % (uint64_t)map_count);
+        if (m < map_lo || m >= map_hi) throw std::runtime_error("entry outside the map range being written");
         Val8 v8{};
         if (e.hc) {
-            Val32 v{};
-            for (int w = 0; w < 4; ++w) { v.fw[w] = e.fw[w]; v.bw[w] = e.bw[w]; }
-            v.cov = e.cov;
-            hc.emplace_back(e.key, v);
+            hc_out.push_back(e);
             v8.cov = 255;                                           // tombstone: "look in the 32-bit map" (:193, :233)
         } else {
             for (int w = 0; w < 4; ++w) { v8.fw[w] = (uint8_t)e.fw[w]; v8.bw[w] = (uint8_t)e.bw[w]; }
             v8.cov = (uint8_t)e.cov;
         }
-        maps[m].emplace_back(e.key, v8);
+        maps[(size_t)(m - map_lo)].emplace_back(e.key, v8);
     }
     // one file per map: independent, so write them with a few threads
-    {
-        unsigned hw = std::thread::hardware_concurrency();
-        const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
-        std::atomic<int> next{0};
-        std::mutex err_m;
-        std::string err;
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nt; ++t)
-            pool.emplace_back([&] {
-                for (int m; (m = next.fetch_add(1)) < map_count;) {
-                    try { write_dump<Val8>(db + "/.map." + std::to_string(m) + ".bin", maps[(size_t)m]); }
-                    catch (const std::exception& e) { std::lock_guard<std::mutex> l(err_m); if (err.empty()) err = e.what(); }
-                }
-            });
-        for (auto& t : pool) t.join();
-        if (!err.empty()) throw std::runtime_error(err);
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
+    std::atomic<int> next{map_lo};
+    std::mutex err_m;
+    std::string err;
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([&] {
+            for (int m; (m = next.fetch_add(1)) < map_hi;) {
+                try { write_dump<Val8>(db + "/.map." + std::to_string(m) + ".bin", maps[(size_t)(m - map_lo)]); }
+                catch (const std::exception& e) { std::lock_guard<std::mutex> l(err_m); if (err.empty()) err = e.what(); }
+            }
+        });
+    for (auto& t : pool) t.join();
+    if (!err.empty()) throw std::runtime_error(err);
+}
+void write_db_finish(const std::string& db, int k, int map_count, const std::vector<kq_entry>& hc_entries) {
+    std::vector<std::pair<uint64_t, Val32>> hc;
+    for (const kq_entry& e : hc_entries) {
+        Val32 v{};
+        for (int w = 0; w < 4; ++w) { v.fw[w] = e.fw[w]; v.bw[w] = e.bw[w]; }
+        v.cov = e.cov;
+        hc.emplace_back(e.key, v);
     }
     write_dump<Val32>(db + "/.map.hc.bin", hc);
     write_index(db, k, map_count);
+}
+
+void write_db(const std::string& db, int k, int map_count, const std::vector<kq_entry>& entries) {
+    std::vector<kq_entry> hc;
+    write_db_maps(db, map_count, 0, map_count, entries, hc);
+    write_db_finish(db, k, map_count, hc);
 }
 
 }  // namespace kqhost

@@ -28,6 +28,12 @@ void read_db(const std::string& db_dir, std::vector<kq_entry>& out, DbIndex* idx
 // Writes all map files.  `entries` = logical entries of the whole table (any order).
 void write_db(const std::string& db_dir, int k, int map_count, const std::vector<kq_entry>& entries);
 
+// The same in pieces, for runs that hold only a range of maps in memory at a time: write the map
+// files of [map_lo, map_hi), collecting high-copy k-mers, and finish with .map.hc.bin + .index.
+void write_db_maps(const std::string& db_dir, int map_count, int map_lo, int map_hi, const std::vector<kq_entry>& entries,
+                   std::vector<kq_entry>& hc_out);
+void write_db_finish(const std::string& db_dir, int k, int map_count, const std::vector<kq_entry>& hc_entries);
+
 // exposed for tests: phmap's 64-bit mix and the submap index it derives
 uint64_t phmap_mix64(uint64_t key);
 unsigned phmap_submap(uint64_t hashval);

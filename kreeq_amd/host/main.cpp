@@ -38,6 +38,7 @@ struct UserInput {                       // reference UserInputKreeq (include/in
     int kmerDepth = -1, maxSpan = 5, maxThreads = 0;
     double maxMem = 0;
     int device = 0;
+    int passes = 1;                      // --passes: count the maps in this many ranges (memory-bounded mode)
 };
 
 int verbose_flag = 0, cmd_flag = 0;
@@ -143,6 +144,10 @@ struct Engine {
         if (want_per_base) per_base.assign(genome.joined.size(), kq_dbgbase{});
         kq_or_die(kq_lookup_sequence(h, genome.joined.data(), genome.joined.size(), ui.covCutOff, 0, (uint16_t)map_count,
                                      want_per_base ? per_base.data() : nullptr, counters));
+        print_qv();
+    }
+
+    void print_qv() {                                                // src/kreeq.cpp:78-106
         if (ui.outFile.find(".") != std::string::npos || ui.outFile == "") {
             const uint64_t missing = counters[0], total = counters[1], edge_missing = counters[2];
             std::cout << "Missing" << "\t" << "Total" << "\t" << "QV" << "\t" << "Error" << "\t" << "k" << "\t" << "Method" << std::endl;
@@ -236,12 +241,74 @@ struct Engine {
 
 uint64_t file_size(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0; }
 
+// Memory-bounded validate: the hash maps are processed in `passes` ranges, re-reading the reads for
+// every range -- the GPU counterpart of the reference's map-range loop (computeMapRange /
+// loadMapRange, src/kreeq.cpp:59-74) and of its spill-to-disk behaviour under -m.  Only 1/passes of
+// the table is resident at a time; summary numbers and QV counters add up over the disjoint ranges.
+int run_passes(Engine& e) {
+    UserInput& ui = e.ui;
+    e.k = ui.kmerLen;
+    if (ui.passes > e.map_count) ui.passes = e.map_count;
+    uint64_t bytes = 0;
+    for (auto& f : ui.inReads) bytes += file_size(f) * (file_ext(f).find("gz") != std::string::npos ? 4 : 1);
+    e.create(std::min<uint64_t>((bytes / 2) / (uint64_t)ui.passes + (1 << 20), 1ull << 31));
+    std::string ext = "stdout";
+    if (ui.outFile != "") ext = file_ext("." + ui.outFile);
+    if (ext == "gfa" || ext == "gfa2" || ext == "gfa.gz" || ext == "gfa2.gz" || ext == "vcf")
+        die("Error: ." + ext + " output (variant search) is not supported by this build");
+    if (!ui.inSequence.empty()) load_genome(ui.inSequence, e.genome);
+    const bool want_stats = ui.outFile.find(".") != std::string::npos || ui.outFile == "" || ext == "kreeq";
+    const bool want_validate = ext != "kreeq" && ext != "hist" && !ui.inSequence.empty();
+    const bool per_base_out = (ext == "kwig" || ext == "bkwig");
+    if (ext == "hist") die("Error: .hist output needs a single pass");
+    if (want_validate && per_base_out) e.per_base.assign(e.genome.joined.size(), kq_dbgbase{});
+    kq_stats sum{};
+    std::vector<kq_entry> hc_all;
+    const unsigned threads = ui.maxThreads > 0 ? (unsigned)ui.maxThreads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    for (int p = 0; p < ui.passes; ++p) {
+        const int lo = (int)((long long)p * e.map_count / ui.passes), hi = (int)((long long)(p + 1) * e.map_count / ui.passes);
+        verbose("Pass " + std::to_string(p + 1) + "/" + std::to_string(ui.passes) + ": maps [" + std::to_string(lo) + "," + std::to_string(hi) + ")");
+        if (p) kq_or_die(kq_clear(e.h));
+        kq_or_die(kq_set_option(e.h, KQ_OPT_COUNT_MAP_RANGE, (int64_t)lo | ((int64_t)hi << 16)));
+        for (auto& f : ui.inReads)
+            read_batches_parallel(f, (size_t)128 << 20, threads, [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
+        kq_stats st;
+        kq_or_die(kq_summary(e.h, &st));
+        sum.total += st.total; sum.unique += st.unique; sum.distinct += st.distinct; sum.edges += st.edges;
+        if (want_validate)
+            kq_or_die(kq_lookup_sequence(e.h, e.genome.joined.data(), e.genome.joined.size(), ui.covCutOff, (uint16_t)lo, (uint16_t)hi,
+                                         per_base_out ? e.per_base.data() : nullptr, e.counters));
+        if (ext == "kreeq") {
+            uint64_t n = 0;
+            kq_or_die(kq_export(e.h, (uint16_t)lo, (uint16_t)hi, nullptr, 0, &n));
+            std::vector<kq_entry> entries((size_t)n);
+            if (n) kq_or_die(kq_export(e.h, (uint16_t)lo, (uint16_t)hi, entries.data(), n, &n));
+            write_db_maps(ui.outFile, e.map_count, lo, hi, entries, hc_all);
+        }
+    }
+    if (ext == "kreeq") write_db_finish(ui.outFile, e.k, e.map_count, hc_all);
+    if (want_stats) {
+        const uint64_t space = e.k < 32 ? (1ull << (2 * e.k)) : 0ull;
+        std::cout << "DBG Summary statistics:\n"
+                  << "Total kmers: " << sum.total << "\n" << "Unique kmers: " << sum.unique << "\n" << "Distinct kmers: " << sum.distinct << "\n"
+                  << "Missing kmers: " << (space - sum.distinct) << "\n" << "Total edges: " << sum.edges << "\n";
+    }
+    if (want_validate) {
+        e.print_qv();
+        if (ext == "kwig") e.write_kwig(ui.outFile);
+        else if (ext == "bkwig") e.write_bkwig(ui.outFile);
+    }
+    kq_destroy(e.h);
+    return EXIT_SUCCESS;
+}
+
 int run(UserInput& ui) {
     Engine e;
     e.ui = ui;
     if (ui.outFile.find(".kreeq") != std::string::npos) e.ui.prefix = ui.outFile;        // src/input.cpp:78-79
     switch (ui.mode) {
         case 0: {                                                    // src/input.cpp:86-118
+            if (!ui.inReads.empty() && ui.passes > 1) return run_passes(e);
             if (!ui.inReads.empty()) {
                 e.k = ui.kmerLen;
                 uint64_t bytes = 0;
@@ -358,7 +425,7 @@ int main(int argc, char** argv) {
             {"max-span", required_argument, 0, 0}, {"out-format", required_argument, 0, 'o'},
             {"input-reads", required_argument, 0, 'r'}, {"tmp-prefix", required_argument, 0, 't'},
             {"max-memory", required_argument, 0, 'm'}, {"threads", required_argument, 0, 'j'},
-            {"device", required_argument, 0, 0},
+            {"device", required_argument, 0, 0}, {"passes", required_argument, 0, 0},
             {"verbose", no_argument, &verbose_flag, 1}, {"cmd", no_argument, &cmd_flag, 1},
             {"version", no_argument, 0, 'v'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
         for (;;) {
@@ -371,6 +438,7 @@ int main(int argc, char** argv) {
                     if (strcmp(long_options[option_index].name, "search-depth") == 0) ui.kmerDepth = atoi(optarg);
                     if (strcmp(long_options[option_index].name, "max-span") == 0) ui.maxSpan = atoi(optarg);
                     if (strcmp(long_options[option_index].name, "device") == 0) ui.device = atoi(optarg);
+                    if (strcmp(long_options[option_index].name, "passes") == 0) ui.passes = std::max(1, atoi(optarg));
                     break;
                 case 'c':
                     if (!is_number(optarg)) { fprintf(stderr, "input '%s' to option -%c must be a number\n", optarg, optopt); return EXIT_FAILURE; }
@@ -408,6 +476,7 @@ int main(int argc, char** argv) {
                     printf("\t-m --max-memory accepted for compatibility.\n");
                     printf("\t-j --threads <n> parser threads for the read files (default: up to 16).\n");
                     printf("\t--device <n> GPU to use (default 0).\n");
+                    printf("\t--passes <n> count the reads n times, one range of the hash maps per pass (bounds HBM use to 1/n of the table).\n");
                     printf("\t-v --version software version.\n");
                     printf("\t--cmd print $0 to stdout.\n");
                     exit(0);

@@ -126,3 +126,22 @@ def test_cli_config1_end_to_end(cli, tmp_path):
     assert out2[6] == "Missing\tTotal\tQV\tError\tk\tMethod"
     missing, total = out2[7].split("\t")[:2]
     assert int(total) == 5_000_000 - k + 1 and int(missing) < 2000
+
+
+@pytest.mark.parametrize("passes", [2, 5, 128])
+def test_cli_passes_match_single_pass(cli, tmp_path, golden_dbs, passes):
+    """--passes n (memory-bounded map-range passes) prints and writes exactly what one pass does"""
+    from tests.golden.make_golden import decode_db
+
+    _, exp = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.3.tst"))
+    reads = [H.golden_input("random1.fastq"), H.golden_input("random2.fastq")]
+    out = run(cli, ["validate", "-f", H.golden_input("random1.fasta"), "-r"] + reads + ["--passes", str(passes)])
+    assert [l for l in out if l] == exp
+    db = str(tmp_path / "u.kreeq")
+    run(cli, ["validate", "-r"] + reads + ["-o", db, "--passes", str(passes)])
+    single = str(tmp_path / "s.kreeq")
+    run(cli, ["validate", "-r"] + reads + ["-o", single])
+    assert decode_db(db) == decode_db(single)
+    bk = str(tmp_path / "o.bkwig")
+    run(cli, ["validate", "-f", H.golden_input("repeat1.fasta"), "-r", H.golden_input("repeat1.fastq"), "-o", bk, "--passes", str(passes)])
+    assert open(bk, "rb").read() == open(H.golden_input("decompressor2.bkwig"), "rb").read()

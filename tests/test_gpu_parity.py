@@ -495,3 +495,31 @@ def test_trusted_capacity_overflow_fails_loudly(kq, path):
     ok.set_option("count_path", path)
     ok.count_batch(batch)
     assert ok.summary()["total"] == 40000 * 130
+
+
+@pytest.mark.parametrize("path", ["partitioned", "direct"])
+def test_count_map_range_filter(kq, O, path):
+    """memory-bounded mode: count the same reads once per map range; the pieces are disjoint and
+    their union is the full database (reference map-range loop, src/kreeq.cpp:59-74)"""
+    batch, genome = H.synth_reads(15000, 150, 50000, seed=88, err=0.01, n_rate=0.003)
+    cpu = O.OracleDB(21, 128)
+    cpu.count_batch(batch, threads=8)
+    full = cpu.export()
+    whole = kq.KreeqDB(21, 128)
+    ctr = np.zeros(3, dtype=np.uint64)
+    for lo, hi in ((0, 1), (1, 70), (70, 128)):
+        piece = kq.KreeqDB(21, 128)
+        piece.set_option("count_path", path)
+        piece.set_option("count_map_range", (lo, hi))
+        piece.count_batch(batch)
+        e = piece.export()
+        m = full["key"] % 128
+        assert H.entries_equal(e, full[(m >= lo) & (m < hi)])
+        c, _ = piece.lookup_sequence(genome, map_lo=lo, map_hi=hi)
+        ctr += c
+        whole.merge(piece)
+    assert H.entries_equal(whole.export(), full)
+    cc, _ = cpu.validate_sequence(genome)
+    assert np.array_equal(ctr, cc)
+    with pytest.raises(kq.KqError):
+        whole.set_option("count_map_range", (5, 5))
