@@ -83,12 +83,13 @@ struct MsShared {
     uint32_t hist[NB_MAX];                   //  8 KiB
     uint32_t loff[NB_MAX];                   //  8 KiB
     unsigned long long gbase[NB_MAX];        // 16 KiB      (76 KiB in all: two workgroups per CU)
-    uint32_t wave_sum[MS_THREADS / 64];
+    uint32_t wave_sum[16];
 };
-constexpr int MS_BINS_PER_THREAD = NB_MAX / MS_THREADS;
 
 // exclusive scan of s.hist[0..nb) into s.loff.  nb <= NB_MAX.
+template <int THREADS>
 __device__ __forceinline__ void ms_scan(MsShared& s, uint32_t nb) {
+    constexpr int MS_BINS_PER_THREAD = NB_MAX / THREADS;
     const int tid = threadIdx.x;
     uint32_t v[MS_BINS_PER_THREAD], sum = 0;
 #pragma unroll
@@ -111,20 +112,23 @@ __device__ __forceinline__ void ms_scan(MsShared& s, uint32_t nb) {
 // s.gbase[b] is the workgroup's PRIVATE running output cursor of bin b (set by the caller before
 // the first round, advanced here), so a round needs no global atomic at all; records of a bin
 // land contiguously at the cursor.  All threads of the block must call it.  nb < NB_MAX.
-template <bool WIDE>
-__device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&rec)[MS_ITEMS], const uint32_t (&aux)[MS_ITEMS],
-                                                 const uint32_t (&bin)[MS_ITEMS], uint32_t nb,
+// THREADS x ITEMS == MS_TILE records per round (256 x 16 for the tile scanner, 512 x 8 where the
+// records come from memory: twice the waves over the same LDS footprint hides more latency).
+template <bool WIDE, int THREADS = MS_THREADS, int ITEMS = MS_ITEMS>
+__device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&rec)[ITEMS], const uint32_t (&aux)[ITEMS],
+                                                 const uint32_t (&bin)[ITEMS], uint32_t nb,
                                                  uint64_t* __restrict__ out, uint8_t* __restrict__ out_aux) {
     const int tid = threadIdx.x;
-    for (uint32_t b = tid; b <= nb; b += MS_THREADS) s.hist[b] = 0;
+    for (uint32_t b = tid; b <= nb; b += THREADS) s.hist[b] = 0;
     __syncthreads();
-    uint32_t rank[MS_ITEMS];
+    static_assert(THREADS * ITEMS == MS_TILE, "round size");
+    uint32_t rank[ITEMS];
 #pragma unroll
-    for (int i = 0; i < MS_ITEMS; ++i) rank[i] = atomicAdd(&s.hist[bin[i]], 1u);
+    for (int i = 0; i < ITEMS; ++i) rank[i] = atomicAdd(&s.hist[bin[i]], 1u);
     __syncthreads();
-    ms_scan(s, nb + 1);
+    ms_scan<THREADS>(s, nb + 1);
 #pragma unroll
-    for (int i = 0; i < MS_ITEMS; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const uint32_t p = s.loff[bin[i]] + rank[i];
         s.stage[p] = rec[i];
         s.sbin[p] = (uint16_t)bin[i];
@@ -132,7 +136,7 @@ __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&r
     }
     __syncthreads();
     const uint32_t total = s.loff[nb];           // records in front of the discard bin
-    for (uint32_t j = tid; j < total; j += MS_THREADS) {
+    for (uint32_t j = tid; j < total; j += THREADS) {
         const uint32_t b = s.sbin[j];
         const uint64_t g = s.gbase[b] + (j - s.loff[b]);
         out[g] = s.stage[j];
@@ -140,7 +144,7 @@ __device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&r
     }
     __syncthreads();
     // advance the cursors; the same thread zeroes hist[b] at the start of the next round
-    for (uint32_t b = tid; b < nb; b += MS_THREADS) s.gbase[b] += s.hist[b];
+    for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] += s.hist[b];
 }
 
 // owner part of a key in the multi-GPU exchange: floor((key % map_count) * n_parts / map_count)
