@@ -76,20 +76,25 @@ __device__ __forceinline__ uint64_t rec_edge_pack(uint64_t rec) {
 }
 __device__ __forceinline__ uint64_t region_id(uint64_t key, uint64_t n_regions) { return hash_region(table_hash(key), n_regions); }
 
+// LDS of one multisplit workgroup.  NBC = bin capacity (incl. the discard bin): 512 keeps the whole
+// struct at 48 KiB (three workgroups per CU) and covers the usual fan-outs; 2048 (72-76 KiB, two per
+// CU) is the general case.
+template <int NBC, bool WIDE>
 struct MsShared {
     uint64_t stage[MS_TILE];                 // 32 KiB
     uint16_t sbin[MS_TILE];                  //  8 KiB
-    uint8_t  saux[MS_TILE];                  //  4 KiB   (WIDE records only)
-    uint32_t hist[NB_MAX];                   //  8 KiB
-    uint32_t loff[NB_MAX];                   //  8 KiB
-    unsigned long long gbase[NB_MAX];        // 16 KiB      (76 KiB in all: two workgroups per CU)
+    uint8_t  saux[WIDE ? MS_TILE : 8];       //  4 KiB   (WIDE records only)
+    uint32_t hist[NBC];
+    uint32_t loff[NBC];
+    unsigned long long gbase[NBC];
     uint32_t wave_sum[16];
 };
 
-// exclusive scan of s.hist[0..nb) into s.loff.  nb <= NB_MAX.
-template <int THREADS>
-__device__ __forceinline__ void ms_scan(MsShared& s, uint32_t nb) {
-    constexpr int MS_BINS_PER_THREAD = NB_MAX / THREADS;
+// exclusive scan of s.hist[0..nb) into s.loff.  nb <= NBC.
+template <int THREADS, class S>
+__device__ __forceinline__ void ms_scan(S& s, uint32_t nb) {
+    constexpr int NBC = (int)(sizeof(s.hist) / sizeof(uint32_t));
+    constexpr int MS_BINS_PER_THREAD = (NBC + THREADS - 1) / THREADS;
     const int tid = threadIdx.x;
     uint32_t v[MS_BINS_PER_THREAD], sum = 0;
 #pragma unroll
@@ -114,8 +119,8 @@ __device__ __forceinline__ void ms_scan(MsShared& s, uint32_t nb) {
 // land contiguously at the cursor.  All threads of the block must call it.  nb < NB_MAX.
 // THREADS x ITEMS == MS_TILE records per round (256 x 16 for the tile scanner, 512 x 8 where the
 // records come from memory: twice the waves over the same LDS footprint hides more latency).
-template <bool WIDE, int THREADS = MS_THREADS, int ITEMS = MS_ITEMS>
-__device__ __forceinline__ void block_multisplit(MsShared& s, const uint64_t (&rec)[ITEMS], const uint32_t (&aux)[ITEMS],
+template <bool WIDE, int THREADS = MS_THREADS, int ITEMS = MS_ITEMS, class S>
+__device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITEMS], const uint32_t (&aux)[ITEMS],
                                                  const uint32_t (&bin)[ITEMS], uint32_t nb,
                                                  uint64_t* __restrict__ out, uint8_t* __restrict__ out_aux) {
     const int tid = threadIdx.x;

@@ -161,13 +161,13 @@ __global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const un
     if (b == cfg.n_coarse) coarse_off[b] = *total;
 }
 // P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
-template <bool WIDE>
+template <bool WIDE, int NBC>
 __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
                                                              PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
                                                              uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
-    __shared__ MsShared s;
+    __shared__ MsShared<NBC, WIDE> s;
     const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
     const uint64_t n_tiles = n_tiles_of(lead, len);
     const uint64_t cols = (uint64_t)gridDim.x * P1_F;
@@ -251,13 +251,13 @@ __global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, L
 }
 // pass B: records -> grouped by (segment, bin); private cursors = group_base + unit prefix
 constexpr int LV_THREADS = 512, LV_ITEMS = 8;       // records come from memory: more waves per LDS footprint
-template <bool WIDE>
+template <bool WIDE, int NBC>
 __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
                                                            const unsigned long long* __restrict__ seg_off,
                                                            const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
                                                            const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out,
                                                            uint8_t* __restrict__ out_aux) {
-    __shared__ MsShared s;
+    __shared__ MsShared<NBC, WIDE> s;
     const uint32_t nb = lv.nb;
     const uint64_t n_units = unit_base[lv.n_seg];
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
@@ -1097,7 +1097,7 @@ static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tile
     plan_cfg(h, &p->cfg);
     p->two_level = p->cfg.g_shift != 0;
     p->n_max = n_max; p->R = p->cfg.n_regions;
-    p->g1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * 2));
+    p->g1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (p1_bins < 512 ? 3 : 2)));
     p->m1_n = (uint64_t)p1_bins * p->g1 * P1_F;
     const uint64_t nb_max = std::max<uint64_t>(1ull << p->cfg.g_shift, p->cfg.n_coarse);
     p->m2_n = (n_max / P2_UNIT + NB_MAX + 2) * nb_max;         // u32 entries, enough for either level
@@ -1138,8 +1138,11 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     hipLaunchKernelGGL(k_p1_hist, dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1);
     scan_u64(h, p->m1, (uint64_t)cfg.n_coarse * p->g1 * P1_F, p->sums, p->total);
     hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, p->m1, p->total, cfg, p->g1, p->seg_off);
-    if (out_aux) hipLaunchKernelGGL(k_p1_scatter<true>, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt);
-    else hipLaunchKernelGGL(k_p1_scatter<false>, dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt);
+    const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
+#define KQ_P1S(W, N) hipLaunchKernelGGL((k_p1_scatter<W, N>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt)
+    if (out_aux) { if (small) KQ_P1S(true, 512); else KQ_P1S(true, NB_MAX); }
+    else         { if (small) KQ_P1S(false, 512); else KQ_P1S(false, NB_MAX); }
+#undef KQ_P1S
 }
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
 // afterwards p->group_base[0..n_seg*nb] are the output offsets
@@ -1152,10 +1155,12 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
     (void)hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
     scan_u64(h, p->group_base, groups + 1, p->sums, p->total + 1);
-    if (wide) hipLaunchKernelGGL(k_lv_scatter<true>, dim3(h->n_cu * 2), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, p->unit_base,
-                                 p->m2, p->group_base, out, out_aux);
-    else hipLaunchKernelGGL(k_lv_scatter<false>, dim3(h->n_cu * 2), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, p->unit_base,
-                            p->m2, p->group_base, out, out_aux);
+    const bool small = lv.nb < 512;
+#define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(h->n_cu * (N == 512 ? 3 : 2)), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
+                                        p->seg_off, p->unit_base, p->m2, p->group_base, out, out_aux)
+    if (wide) { if (small) KQ_LVS(true, 512); else KQ_LVS(true, NB_MAX); }
+    else      { if (small) KQ_LVS(false, 512); else KQ_LVS(false, NB_MAX); }
+#undef KQ_LVS
 }
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0;
