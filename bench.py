@@ -131,7 +131,7 @@ def main():
                        "genome_bp": GENOME_LEN, "error_rate": ERR, "table_capacity_kmers": args.capacity, "count_path": args.path, "sharding": f"bucket x{world}" if world > 1 else "none"},
             "total_kmers_per_step": kmers_per_rank * world, "distinct_kmers": summ["distinct"],
             "distinct_kmers_per_s": summ["distinct"] * args.steps / dt,
-            "roofline": {"bound": "hbm", "kernel": ("count_batch: k_p1_hist+k_p1_scatter+k_p2_hist+k_p2_scatter+k_count_regions" if args.path != "direct"
+            "roofline": {"bound": "hbm", "kernel": ("count_batch launch set: k_p1_hist+k_p1_scatter+k_lv_hist+k_lv_scatter+k_count_regions (+scans)" if args.path != "direct"
                                                     else "k_count_direct") if world == 1 and not args.sharded else "owner split (k_p1_*) + all_to_all + k_lv_* + k_count_regions",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": kern_ms},
