@@ -214,6 +214,32 @@ struct Engine {
                 }
             }
     }
+    // .bed / .csvtable per-base table (src/kreeq-output.cpp:138-241): for every position the k most
+    // recent values of cov / fw-edge / bw-edge, oldest first.  No fixture of the reference pins this
+    // text (parity unpinned); it is restated from the writer's source.
+    void write_table(const std::string& path, const std::string& ext) {
+        char colSep = ',', entrySep = ',';
+        if (ext == "bed") colSep = '\t', entrySep = ':';
+        std::ofstream ofs(path);
+        for (size_t s = 0; s < genome.seqs.size(); ++s) {
+            for (auto& seg : segments_of(genome.seqs[s].seq)) {
+                std::vector<uint32_t> kc(k - 1, 0), ef(k - 1, 0), eb(k - 1, 0);
+                const kq_dbgbase* b = per_base.data() + genome.offset[s] + seg.first;
+                for (uint64_t i = 0; i < seg.second; ++i) {
+                    ofs << genome.seqs[s].header << colSep << (seg.first + i) << colSep;
+                    kc.push_back(b[i].cov);
+                    ef.push_back(b[i].isFw ? b[i].fw : b[i].bw);
+                    eb.push_back(b[i].isFw ? b[i].bw : b[i].fw);
+                    for (auto* v : {&kc, &ef, &eb}) {
+                        for (int c = 0; c < k; ++c) { ofs << std::to_string((*v)[(size_t)c]); if (c < k - 1) ofs << entrySep; }
+                        if (v != &eb) ofs << colSep;
+                        v->erase(v->begin());
+                    }
+                    ofs << "\n";
+                }
+            }
+        }
+    }
     void write_hist(const std::string& path) {                       // gfalibs printHist (format not pinned by any fixture)
         uint64_t n = 0;
         kq_or_die(kq_histogram(h, nullptr, nullptr, 0, &n));
@@ -228,13 +254,14 @@ struct Engine {
         if (ui.outFile != "") ext = file_ext("." + ui.outFile);
         if (ui.outFile.find(".") != std::string::npos || ui.outFile == "" || ext == "kreeq") { stats(); verbose("Summary computed"); }
         verbose("Writing ouput: " + ui.outFile);
-        const bool per_base_out = (ext == "kwig" || ext == "bkwig");
+        const bool per_base_out = (ext == "kwig" || ext == "bkwig" || ext == "bed" || ext == "csvtable");
         if (ext == "gfa" || ext == "gfa2" || ext == "gfa.gz" || ext == "gfa2.gz" || ext == "vcf")
             die("Error: ." + ext + " output (variant search) is not supported by this build");
         if (ext != "kreeq" && ext != "hist" && ui.mode == 0) validate_sequences(per_base_out);
         if (ext == "kreeq") { write_kreeq_db(ui.outFile); verbose("Database written"); }
         else if (ext == "kwig") write_kwig(ui.outFile);
         else if (ext == "bkwig") write_bkwig(ui.outFile);
+        else if (ext == "bed" || ext == "csvtable") write_table(ui.outFile, ext);
         else if (ext == "hist") write_hist(ui.outFile);
     }
 };
@@ -259,7 +286,7 @@ int run_passes(Engine& e) {
     if (!ui.inSequence.empty()) load_genome(ui.inSequence, e.genome);
     const bool want_stats = ui.outFile.find(".") != std::string::npos || ui.outFile == "" || ext == "kreeq";
     const bool want_validate = ext != "kreeq" && ext != "hist" && !ui.inSequence.empty();
-    const bool per_base_out = (ext == "kwig" || ext == "bkwig");
+    const bool per_base_out = (ext == "kwig" || ext == "bkwig" || ext == "bed" || ext == "csvtable");
     if (ext == "hist") die("Error: .hist output needs a single pass");
     if (want_validate && per_base_out) e.per_base.assign(e.genome.joined.size(), kq_dbgbase{});
     kq_stats sum{};
@@ -297,6 +324,7 @@ int run_passes(Engine& e) {
         e.print_qv();
         if (ext == "kwig") e.write_kwig(ui.outFile);
         else if (ext == "bkwig") e.write_bkwig(ui.outFile);
+        else if (ext == "bed" || ext == "csvtable") e.write_table(ui.outFile, ext);
     }
     kq_destroy(e.h);
     return EXIT_SUCCESS;

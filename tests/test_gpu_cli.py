@@ -145,3 +145,38 @@ def test_cli_passes_match_single_pass(cli, tmp_path, golden_dbs, passes):
     bk = str(tmp_path / "o.bkwig")
     run(cli, ["validate", "-f", H.golden_input("repeat1.fasta"), "-r", H.golden_input("repeat1.fastq"), "-o", bk, "--passes", str(passes)])
     assert open(bk, "rb").read() == open(H.golden_input("decompressor2.bkwig"), "rb").read()
+
+
+def test_bed_table(cli, tmp_path):
+    """.bed per-base table: windows of the k latest cov / fw / bw values (no reference fixture: the
+    text is checked against the oracle's per-base values, format restated from src/kreeq-output.cpp:138-241)"""
+    import numpy as np
+
+    from oracle import oracle as O
+    from tests.test_oracle_golden import per_base_triplets
+
+    out = str(tmp_path / "o.bed")
+    run(cli, ["validate", "-f", H.golden_input("decompressor1.fasta"), "-r", H.golden_input("random1.fastq"), "-o", out])
+    db = O.OracleDB(21, 128)
+    db.count_batch(H.reads_batch([H.golden_input("random1.fastq")]))
+    lines = open(out).read().split("\n")
+    li = 0
+    for hdr, seq in H.read_fastx(H.golden_input("decompressor1.fasta")):
+        _, pb = db.validate_sequence(seq, per_base=True)
+        trip = per_base_triplets(pb)
+        i = 0
+        while i < len(seq):
+            if seq[i:i + 1].upper() not in (b"A", b"C", b"G", b"T"):
+                i += 1
+                continue
+            j = i
+            while j < len(seq) and seq[j:j + 1].upper() in (b"A", b"C", b"G", b"T"):
+                j += 1
+            hist = np.zeros((20, 3), dtype=np.uint32)
+            for p in range(i, j):
+                hist = np.vstack([hist, trip[p:p + 1]])
+                cols = [":".join(str(x) for x in hist[-21:, c]) for c in range(3)]
+                assert lines[li] == "\t".join([hdr, str(p)] + cols), (hdr, p)
+                li += 1
+            i = j
+    assert lines[li:] == [""]
