@@ -335,10 +335,14 @@ __global__ __launch_bounds__(1024) void k_scan_apply(unsigned long long* __restr
 // P3: one workgroup per table region.  The region's slots (REGION_SLOTS x 24 B) are staged in LDS, all
 // records of the region are applied with LDS atomics (same two-tier rule as table_add), and the
 // image is streamed back.  Global atomics only for the rare high-copy tier and the two totals.
-constexpr int P3_THREADS = 512;
-template <bool WIDE>
-__global__ __launch_bounds__(P3_THREADS, 6) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
-                                                              int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty) {
+constexpr int P3_THREADS = 1024;        // two 48 KiB images per CU at the full 32 waves: the walk is a chain of dependent LDS round trips per record, so fewer records per lane wins (256 / 512 / 1024 threads: 1146 / 755 / 700 us)
+// Two instantiations share the regions: HOT = false takes the ordinary ones (deep record prefetch, no
+// folding state: fits the 80 VGPRs that let three workgroups share a CU) and appends the skewed ones
+// to hot_list; HOT = true then walks that list with the folding loop.
+template <bool WIDE, bool HOT>
+__global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 8) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
+                                                              int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty,
+                                                              unsigned long long* __restrict__ hot_list /*[0] = count, then region ids*/) {
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
     __shared__ unsigned long long s_new, s_kmers;
     // high-copy tier of this region, aggregated in LDS: a repeat k-mer with millions of instances
@@ -347,9 +351,17 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_count_regions(TableView t, co
     __shared__ uint64_t s_hckey[HC_LDS];
     __shared__ uint32_t s_hccnt[HC_LDS][8];
     const int tid = threadIdx.x;
-    for (uint64_t r = blockIdx.x; r < t.n_regions; r += gridDim.x) {
+    const uint64_t n_work = HOT ? hot_list[0] : t.n_regions;
+    for (uint64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const uint64_t r = HOT ? hot_list[1 + w] : w;
         const uint64_t lo = region_base[r], hi = region_base[r + 1];
         if (lo == hi) continue;                                         // block-uniform
+        // folding costs a ballot + shuffle per iteration: only regions that receive far more records than
+        // they have slots (skew, or very deep coverage) take that path, in the second launch
+        if (!HOT && hi - lo > 32ull * REGION_SLOTS) {
+            if (tid == 0) hot_list[1 + atomicAdd(&hot_list[0], 1ull)] = r;
+            continue;
+        }
         if (tid < HC_LDS) {
             s_hckey[tid] = EMPTY_KEY;
 #pragma unroll
@@ -417,8 +429,8 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_count_regions(TableView t, co
         bool have_acc = false;
         uint64_t acc_key = 0;
         uint32_t acc_cnt = 0, acc_e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        // records are prefetched two iterations ahead (6 waves per SIMD = three 48 KiB images per CU need <= 80 VGPRs): a skewed region is walked by ONE workgroup,
-        // which must not pay a global-load latency per iteration
+        // records are prefetched PF iterations ahead: the walk must not pay a global-load latency per
+        // iteration (measured: with 2 in flight the kernel waited on record loads most of the time)
         constexpr int PF = 2;
         uint64_t pf_rec[PF];
         uint32_t pf_aux[PF];
@@ -480,9 +492,7 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_count_regions(TableView t, co
         }
         if (have_acc && (tid & 63) == 0) apply(acc_key, acc_e, acc_cnt);
         };
-        // folding costs a ballot + shuffle per iteration: only regions that receive far more records than
-        // they have slots (skew, or very deep coverage) take that path
-        if (hi - lo > 32ull * REGION_SLOTS) run(std::true_type{}); else run(std::false_type{});
+        run(std::integral_constant<bool, HOT>{});
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { n_new += __shfl_down(n_new, o, 64); n_ok += __shfl_down(n_ok, o, 64); }
         if ((tid & 63) == 0) { if (n_new) atomicAdd(&s_new, (unsigned long long)n_new); if (n_ok) atomicAdd(&s_kmers, (unsigned long long)n_ok); }
@@ -1074,7 +1084,7 @@ struct PartPlan {
     // device pointers into h->part
     uint64_t *recs1, *recs2;
     uint8_t *aux1, *aux2;     // WIDE records: edge bytes travelling with recs1 / recs2
-    unsigned long long *m1, *seg_off, *unit_base, *group_base, *sums, *total;
+    unsigned long long *m1, *seg_off, *unit_base, *group_base, *sums, *total, *hot;
     uint32_t* m2;
 };
 static void plan_cfg(const kq_handle* h, PartCfg* cfg) {
@@ -1104,7 +1114,7 @@ static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tile
     p->groups_n = std::max<uint64_t>(p->R, (uint64_t)p->cfg.n_coarse << p->cfg.g_shift) + 2;
     p->sums_n = std::max(p->m1_n, p->groups_n) / SCAN_CHUNK + 2;
     const uint64_t aux_words = (n_max + 7) / 8 + 1;
-    const size_t words = (size_t)(2 * n_max + 2 * aux_words + p->m1_n + 2 * (NB_MAX + 2) + p->groups_n + p->sums_n + 4 + (p->m2_n + 1) / 2);
+    const size_t words = (size_t)(2 * n_max + 2 * aux_words + p->m1_n + 2 * (NB_MAX + 2) + p->groups_n + p->sums_n + 4 + (p->R + 2) + (p->m2_n + 1) / 2);
     int rc = ensure_buf(&h->part, &h->part_bytes, words * 8);
     if (rc) return rc;
     p->recs1 = (uint64_t*)h->part;
@@ -1117,7 +1127,8 @@ static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tile
     p->group_base = p->unit_base + NB_MAX + 2;
     p->sums = p->group_base + p->groups_n;
     p->total = p->sums + p->sums_n;
-    p->m2 = (uint32_t*)(p->total + 4);
+    p->hot = p->total + 4;
+    p->m2 = (uint32_t*)(p->hot + p->R + 2);
     return KQ_OK;
 }
 // exclusive scan of n u64 on the device (in place); *total (device) receives the sum
@@ -1171,10 +1182,18 @@ static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
     return lv;
 }
 static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint8_t* sorted_aux, int aux_fmt, const unsigned long long* base) {
-    if (sorted_aux) hipLaunchKernelGGL(k_count_regions<true>, dim3(grid_for(h, p->R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted,
-                                       sorted_aux, aux_fmt, base, h->table_empty ? 1 : 0);
-    else hipLaunchKernelGGL(k_count_regions<false>, dim3(grid_for(h, p->R, 1)), dim3(P3_THREADS), 0, h->stream, h->view(), sorted, sorted_aux,
-                            aux_fmt, base, h->table_empty ? 1 : 0);
+    // hot list lives in the (now free) count matrix area: [0] = count, then up to R region ids
+    unsigned long long* hot = p->hot;
+    (void)hipMemsetAsync(hot, 0, 8, h->stream);
+    const dim3 grid(grid_for(h, p->R, 1)), grid_hot(h->n_cu), block(P3_THREADS);
+    const int empty = h->table_empty ? 1 : 0;
+    if (sorted_aux) {
+        hipLaunchKernelGGL((k_count_regions<true, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
+        hipLaunchKernelGGL((k_count_regions<true, true>), grid_hot, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
+    } else {
+        hipLaunchKernelGGL((k_count_regions<false, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
+        hipLaunchKernelGGL((k_count_regions<false, true>), grid_hot, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
+    }
 }
 
 // partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
