@@ -141,11 +141,25 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     }
     __syncthreads();
     const uint32_t total = s.loff[nb];           // records in front of the discard bin
-    for (uint32_t j = tid; j < total; j += THREADS) {
-        const uint32_t b = s.sbin[j];
-        const uint64_t g = s.gbase[b] + (j - s.loff[b]);
-        out[g] = s.stage[j];
-        if (WIDE) out_aux[g] = s.saux[j];
+    // fully unrolled so that the LDS reads of all ITEMS positions are in flight together (a rolled
+    // loop is a chain of three dependent LDS round trips per record)
+    uint32_t cb[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) { const uint32_t j = tid + it * THREADS; cb[it] = j < total ? s.sbin[j] : 0u; }
+    uint64_t cg[ITEMS], cv[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t j = tid + it * THREADS;
+        cg[it] = s.gbase[cb[it]] + (j - s.loff[cb[it]]);
+        cv[it] = s.stage[j < MS_TILE ? j : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t j = tid + it * THREADS;
+        if (j < total) {
+            out[cg[it]] = cv[it];
+            if (WIDE) out_aux[cg[it]] = s.saux[j];
+        }
     }
     __syncthreads();
     // advance the cursors; the same thread zeroes hist[b] at the start of the next round

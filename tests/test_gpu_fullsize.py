@@ -98,3 +98,23 @@ def test_union_is_linear_full_size(workload):
     whole.count_batch_dev(d_reads.data_ptr(), d_reads.numel())
     a.merge(b)
     assert a.summary(with_hist=True) == whole.summary(with_hist=True)
+
+
+def test_hifi_length_reads_k31():
+    """BASELINE configs[4] shape at small scale: 15 kbp reads, k=31, 0.1 % substitutions (WIDE records)"""
+    import kreeq_amd
+    from kreeq_amd import synth
+    from oracle import oracle as O
+    from tests import helpers as H
+
+    genome = synth.genome_codes(3_000_000, seed=4)
+    reads = synth.reads_batch(genome, 2000, 15000, seed=5, err=0.001, chunk=500).tobytes()
+    gpu, cpu = kreeq_amd.KreeqDB(31, 128), O.OracleDB(31, 128)
+    gpu.count_batch(reads)
+    cpu.count_batch(reads, threads=16)
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(gpu.export(), cpu.export())
+    asm = synth.codes_to_ascii(synth.mutate(genome, 1e-4, seed=6)).tobytes()
+    cg, _ = gpu.lookup_sequence(asm)
+    cc, _ = cpu.validate_sequence(asm, threads=16)
+    assert np.array_equal(cg, cc)
