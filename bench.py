@@ -41,8 +41,11 @@ def main():
     ap.add_argument("--capacity", type=int, default=24_000_000,
                     help="expected distinct k-mers per GPU (table = capacity/0.6 slots; the workload has 17.7 M)")
     ap.add_argument("--path", choices=["auto", "direct", "partitioned"], default="auto")
+    ap.add_argument("-k", type=int, default=K, help="k-mer length (default 21 = BASELINE.json's metric)")
+    ap.add_argument("--read-len", type=int, default=READ_LEN)
     ap.add_argument("--sharded", action="store_true", help="with one GPU: still run the N>1 code path (owner split -> insert)")
     args = ap.parse_args()
+    K_, RL = args.k, args.read_len
 
     import torch
     import torch.distributed as dist
@@ -65,19 +68,19 @@ def main():
 
     # synthetic input: same genome everywhere, a different read shard per rank
     genome = synth.genome_codes(GENOME_LEN, seed=1)
-    reads_np = synth.reads_batch(genome, args.reads, READ_LEN, seed=2 + 1000 * rank, err=ERR)
+    reads_np = synth.reads_batch(genome, args.reads, RL, seed=2 + 1000 * rank, err=ERR)
     reads = torch.from_numpy(reads_np).to(dev)
-    kmers_per_rank = args.reads * (READ_LEN - K + 1)
+    kmers_per_rank = args.reads * (RL - K_ + 1)
 
     # table sized for the records this rank will own (weak scaling: ~ one batch worth)
     # run on an explicit (non-null) stream: the handle launches on it and the HIP events below are
     # recorded on the same stream, so they bracket exactly the kernels of one step
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
-    engine = GpuEngine(K, 128, local_rank, capacity_hint=args.capacity)
+    engine = GpuEngine(K_, 128, local_rank, capacity_hint=args.capacity)
     engine.db.set_option("trust_capacity", 1)     # the hint is an upper bound of the distinct k-mers (jellyfish -s style)
     engine.db.set_option("count_path", args.path)
-    counter = ShardedCounter(engine, K, 128, sharded_path=args.sharded)
+    counter = ShardedCounter(engine, K_, 128, sharded_path=args.sharded)
     counter.force_exchange = args.sharded and dist.is_initialized()      # rehearse the RCCL exchange even at world size 1
 
     def step():
@@ -124,10 +127,10 @@ def main():
         if os.path.exists(tp) and world == 1 and args.reads == N_READS:
             traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
         out = {
-            "metric": "distinct+total k-mers/sec at k=21 (count path)", "value": value, "unit": "k-mers/s",
+            "metric": f"distinct+total k-mers/sec at k={K_} (count path)", "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.reads} x {READ_LEN} bp reads per GPU, k={K}, count-only (configs[1])",
+            "config": {"workload": f"synthetic {args.reads} x {RL} bp reads per GPU, k={K_}, count-only" + (" (configs[1])" if (K_, RL, args.reads) == (K, READ_LEN, N_READS) else ""),
                        "genome_bp": GENOME_LEN, "error_rate": ERR, "table_capacity_kmers": args.capacity, "count_path": args.path, "sharding": f"bucket x{world}" if world > 1 else "none"},
             "total_kmers_per_step": kmers_per_rank * world, "distinct_kmers": summ["distinct"],
             "distinct_kmers_per_s": summ["distinct"] * args.steps / dt,
@@ -137,14 +140,14 @@ def main():
                          "traffic": traffic, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": kern_ms},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(reads_np)
+            out["cpu_baseline"] = cpu_baseline(reads_np, K_, RL)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(reads_np):
+def cpu_baseline(reads_np, k=K, read_len=READ_LEN):
     """The CPU restatement of the reference algorithm (oracle/, kind "port": the reference itself
     cannot be built -- gfalibs is absent) timed on this host's cores on the same batch."""
     from oracle import oracle as O
@@ -154,13 +157,13 @@ def cpu_baseline(reads_np):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 128))      # one job per map in loop 2: more than map_count threads cannot help
-    sample_reads = min(N_READS, (len(reads_np) + 1) // (READ_LEN + 1))
-    buf = reads_np[:sample_reads * (READ_LEN + 1) - 1].tobytes()
-    db = O.OracleDB(K, 128)
+    sample_reads = min(N_READS, (len(reads_np) + 1) // (read_len + 1))
+    buf = reads_np[:sample_reads * (read_len + 1) - 1].tobytes()
+    db = O.OracleDB(k, 128)
     t0 = time.perf_counter()
     db.count_batch(buf, threads=cores)
     dt = time.perf_counter() - t0
-    n = sample_reads * (READ_LEN - K + 1)
+    n = sample_reads * (read_len - k + 1)
     return {"value": n / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
             "sample": f"{sample_reads} of the same reads ({n} k-mers), {dt:.1f} s wall, input in memory"}
 
