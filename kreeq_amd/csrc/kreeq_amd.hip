@@ -235,19 +235,26 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
     }
 }
 // per output group (segment b, bin): exclusive prefix of its counts over the segment's units
-// (in place), group total out
+// (in place), group total out.  One WAVE per group: a segment can have thousands of units (the
+// flat -> coarse level has a single segment), so the prefix runs 64 units at a time.
 __global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, LevelCfg lv, const unsigned long long* __restrict__ unit_base,
                                                     unsigned long long* __restrict__ group_count) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= (uint64_t)lv.n_seg * lv.nb) return;
+    const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (r >= (uint64_t)lv.n_seg * lv.nb) return;                     // wave-uniform
     const uint32_t b = (uint32_t)(r / lv.nb), bin = (uint32_t)(r % lv.nb);
+    const uint64_t u0 = unit_base[b], u1 = unit_base[b + 1];
     unsigned long long run = 0;
-    for (uint64_t u = unit_base[b]; u < unit_base[b + 1]; ++u) {
-        const uint32_t c = m2[u * lv.nb + bin];
-        m2[u * lv.nb + bin] = (uint32_t)run;         // a group holds < 2^32 records of one batch
-        run += c;
+    for (uint64_t base = u0; base < u1; base += 64) {
+        const uint64_t u = base + lane;
+        const uint32_t c = u < u1 ? m2[u * lv.nb + bin] : 0u;
+        unsigned long long incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long n = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += n; }
+        if (u < u1) m2[u * lv.nb + bin] = (uint32_t)(run + incl - c);   // a group holds < 2^32 records of one batch
+        run += __shfl(incl, 63, 64);
     }
-    group_count[r] = run;
+    if (lane == 0) group_count[r] = run;
 }
 // pass B: records -> grouped by (segment, bin); private cursors = group_base + unit prefix
 constexpr int LV_THREADS = 512, LV_ITEMS = 8;       // records come from memory: more waves per LDS footprint
@@ -1163,7 +1170,7 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, lv, p->unit_base);
     if (wide) hipLaunchKernelGGL(k_lv_hist<true>, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     else hipLaunchKernelGGL(k_lv_hist<false>, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
-    hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
+    hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
     (void)hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
     scan_u64(h, p->group_base, groups + 1, p->sums, p->total + 1);
     const bool small = lv.nb < 512;
