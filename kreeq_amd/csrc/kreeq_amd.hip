@@ -1168,13 +1168,16 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     const bool wide = in_aux != nullptr;
     const uint64_t groups = (uint64_t)lv.n_seg * lv.nb;
     hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, lv, p->unit_base);
-    if (wide) hipLaunchKernelGGL(k_lv_hist<true>, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
-    else hipLaunchKernelGGL(k_lv_hist<false>, dim3(h->n_cu * 8), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    // one workgroup per work unit (upper bound of the unit count; surplus workgroups exit at once):
+    // the hardware dispatcher balances them, a fixed grid looping over units left a 30 % tail
+    const unsigned unit_grid = (unsigned)std::min<uint64_t>(p->n_max / P2_UNIT + lv.n_seg + 1, 1u << 30);
+    if (wide) hipLaunchKernelGGL(k_lv_hist<true>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    else hipLaunchKernelGGL(k_lv_hist<false>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
     (void)hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
     scan_u64(h, p->group_base, groups + 1, p->sums, p->total + 1);
     const bool small = lv.nb < 512;
-#define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(h->n_cu * (N == 512 ? 3 : 2)), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
+#define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
                                         p->seg_off, p->unit_base, p->m2, p->group_base, out, out_aux)
     if (wide) { if (small) KQ_LVS(true, 512); else KQ_LVS(true, NB_MAX); }
     else      { if (small) KQ_LVS(false, 512); else KQ_LVS(false, NB_MAX); }
@@ -1192,7 +1195,7 @@ static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint
     // hot list lives in the (now free) count matrix area: [0] = count, then up to R region ids
     unsigned long long* hot = p->hot;
     (void)hipMemsetAsync(hot, 0, 8, h->stream);
-    const dim3 grid(grid_for(h, p->R, 1)), grid_hot(h->n_cu), block(P3_THREADS);
+    const dim3 grid((unsigned)std::min<uint64_t>(p->R, 1u << 30)), grid_hot(h->n_cu), block(P3_THREADS);   // one workgroup per region: dispatcher-balanced
     const int empty = h->table_empty ? 1 : 0;
     if (sorted_aux) {
         hipLaunchKernelGGL((k_count_regions<true, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
