@@ -113,6 +113,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # per-stage HIP-event times of one extra (untimed) step, for the roofline breakdown
+    stages = None
+    if world == 1 and not args.sharded and args.path != "direct":
+        engine.db.set_option("profile", 1)
+        step()
+        stages = engine.db.profile()
+        engine.db.set_option("profile", 0)
+
     # correctness guard inside the bench: totals must match the closed form
     summ = counter.summary()
     assert summ["total"] == kmers_per_rank * world, (summ, kmers_per_rank, world)
@@ -137,7 +145,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": ("count_batch launch set: k_p1_hist+k_p1_scatter+k_lv_hist+k_lv_scatter+k_count_regions (+scans)" if args.path != "direct"
                                                     else "k_count_direct") if world == 1 and not args.sharded else "owner split (k_p1_*) + all_to_all + k_lv_* + k_count_regions",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": kern_ms},
+                         "traffic": traffic, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": kern_ms, "stage_ms": stages},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(reads_np, K_, RL)

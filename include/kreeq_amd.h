@@ -108,9 +108,12 @@ void* kq_get_stream(kq_handle* h);
  *   KQ_OPT_COUNT_MAP_RANGE value = lo | hi << 16: kq_count_batch(_dev) keeps only k-mers whose map index
  *                          key % map_count lies in [lo, hi).  This is the reference's memory-bounded mode
  *                          (process the maps in ranges, src/kreeq.cpp:59-74; README "HPC" runs + union):
- *                          count the same reads once per range into separate databases, then union. */
-enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4 };
+ *                          count the same reads once per range into separate databases, then union.
+ *   KQ_OPT_PROFILE         value != 0: HIP events are recorded around the stages of the partitioned count;
+ *                          kq_get_profile() returns "stage=ms;..." for the last batch (measurement aid) */
+enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4, KQ_OPT_PROFILE = 5 };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
+int  kq_get_profile(kq_handle* h, char* buf, uint64_t cap);
 int  kq_sync(kq_handle* h);
 int  kq_get_info(kq_handle* h, kq_info* out);
 const char* kq_last_error(void);

@@ -12,7 +12,7 @@ ENTRY_DTYPE = np.dtype([("key", "<u8"), ("fw", "<u4", 4), ("bw", "<u4", 4), ("co
 DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw", "u1"), ("pad", "u1", 3)])
 
 # every symbol include/kreeq_amd.h declares
-SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_get_info", "kq_last_error",
+SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_get_profile", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_get_info", "kq_last_error",
            "kq_abi_version", "kq_device_available", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
            "kq_emit_partitioned_dev", "kq_emit_packed_dev", "kq_insert_packed_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
            "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_merge", "kq_import", "kq_export"]
@@ -81,6 +81,7 @@ def load():
     L.kq_clear.argtypes = [vp]
     L.kq_set_stream.argtypes = [vp, vp]
     L.kq_set_option.argtypes = [vp, ci, C.c_int64]
+    L.kq_get_profile.argtypes = [vp, C.c_char_p, u64]
     L.kq_get_stream.argtypes = [vp]
     L.kq_get_stream.restype = vp
     L.kq_sync.argtypes = [vp]
@@ -146,7 +147,7 @@ class KreeqDB:
 
     def set_option(self, option, value):
         """option: 'trust_capacity' | 'count_path' ('auto'|'direct'|'partitioned') | 'slice_kmers' | 'count_map_range' ((lo, hi))"""
-        opt = {"trust_capacity": 1, "count_path": 2, "slice_kmers": 3, "count_map_range": 4}[option]
+        opt = {"trust_capacity": 1, "count_path": 2, "slice_kmers": 3, "count_map_range": 4, "profile": 5}[option]
         if option == "count_map_range":
             value = int(value[0]) | (int(value[1]) << 16)
         if option == "count_path":
@@ -155,6 +156,12 @@ class KreeqDB:
 
     def clear(self):
         _check(load().kq_clear(self._h))
+
+    def profile(self):
+        """{stage: ms} of the last partitioned count (needs set_option('profile', 1))"""
+        buf = C.create_string_buffer(1024)
+        _check(load().kq_get_profile(self._h, buf, 1024))
+        return {k: float(v) for k, v in (kv.split("=") for kv in buf.value.decode().split(";") if kv)}
 
     def info(self):
         i = Info()

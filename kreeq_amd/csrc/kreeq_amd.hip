@@ -794,11 +794,15 @@ struct kq_handle {
     int count_path = 0;              // KQ_OPT_COUNT_PATH: 0 auto, 1 direct (global atomics), 2 partitioned
     uint64_t slice_kmers = 1ull << 28;   // KQ_OPT_SLICE_KMERS
     uint32_t filt_lo = 0, filt_hi = 0;   // KQ_OPT_COUNT_MAP_RANGE (set to [0, map_count) at creation)
+    bool profile = false;                // KQ_OPT_PROFILE: HIP events around the stages of the partitioned count
+    std::vector<std::pair<const char*, hipEvent_t>> marks;
     void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
 
     TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; return v; }
     uint64_t n_slots() const { return n_regions << REGION_SHIFT; }
 };
+
+static void marks_reset(kq_handle* h);
 
 static int grid_for(const kq_handle* h, uint64_t work_items, int per_block) {
     uint64_t blocks = (work_items + per_block - 1) / per_block;
@@ -1019,6 +1023,7 @@ void kq_destroy(kq_handle* h) {
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->stage) (void)hipFree(h->stage);
     if (h->part) (void)hipFree(h->part);
+    marks_reset(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -1053,11 +1058,28 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             if (lo >= hi || hi > h->map_count) return fail(KQ_ERR_INVALID, "map range [%lld,%lld) outside [0,%d]", (long long)lo, (long long)hi, h->map_count);
             h->filt_lo = (uint32_t)lo; h->filt_hi = (uint32_t)hi; return KQ_OK;
         }
+        case KQ_OPT_PROFILE: h->profile = value != 0; if (!h->profile) marks_reset(h); return KQ_OK;
         case KQ_OPT_SLICE_KMERS:
             if (value < 1) return fail(KQ_ERR_INVALID, "KQ_OPT_SLICE_KMERS must be positive");
             h->slice_kmers = (uint64_t)value; return KQ_OK;
         default: return fail(KQ_ERR_INVALID, "unknown option %d", option);
     }
+}
+int kq_get_profile(kq_handle* h, char* buf, uint64_t cap) {
+    if (!h || !buf || !cap) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipStreamSynchronize(h->stream));
+    std::string out;
+    for (size_t i = 1; i < h->marks.size(); ++i) {
+        float ms = 0;
+        HIPC(hipEventElapsedTime(&ms, h->marks[i - 1].second, h->marks[i].second));
+        char tmp[96];
+        snprintf(tmp, sizeof tmp, "%s%s=%.4f", out.empty() ? "" : ";", h->marks[i].first, ms);
+        out += tmp;
+    }
+    if (out.size() + 1 > cap) return fail(KQ_ERR_CAPACITY, "profile buffer too small: need %zu", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return KQ_OK;
 }
 void* kq_get_stream(kq_handle* h) { return h ? (void*)h->stream : nullptr; }
 int kq_sync(kq_handle* h) {
@@ -1151,16 +1173,31 @@ static void scan_u64(kq_handle* h, unsigned long long* a, uint64_t n, unsigned l
 }
 // P1 on bases with the given bin function; afterwards p->seg_off[0..bins] are the bucket offsets
 // (seg_off[bins] = number of records) and `out` holds the records grouped by bin
+// stage marker of the last partitioned count (KQ_OPT_PROFILE): one HIP event per call, on the handle's stream
+static void mark(kq_handle* h, const char* name) {
+    if (!h->profile) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, h->stream);
+    h->marks.emplace_back(name, e);
+}
+static void marks_reset(kq_handle* h) {
+    for (auto& m : h->marks) (void)hipEventDestroy(m.second);
+    h->marks.clear();
+}
+
 static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er, uint64_t* out,
                    uint8_t* out_aux, int aux_fmt) {
     hipLaunchKernelGGL(k_p1_hist, dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1);
     scan_u64(h, p->m1, (uint64_t)cfg.n_coarse * p->g1 * P1_F, p->sums, p->total);
     hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, p->m1, p->total, cfg, p->g1, p->seg_off);
+    mark(h, "k_p1_hist+scan");
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
 #define KQ_P1S(W, N) hipLaunchKernelGGL((k_p1_scatter<W, N>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt)
     if (out_aux) { if (small) KQ_P1S(true, 512); else KQ_P1S(true, NB_MAX); }
     else         { if (small) KQ_P1S(false, 512); else KQ_P1S(false, NB_MAX); }
 #undef KQ_P1S
+    mark(h, "k_p1_scatter");
 }
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
 // afterwards p->group_base[0..n_seg*nb] are the output offsets
@@ -1176,12 +1213,14 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
     (void)hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
     scan_u64(h, p->group_base, groups + 1, p->sums, p->total + 1);
+    mark(h, "k_lv_hist+offsets+scan");
     const bool small = lv.nb < 512;
 #define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
                                         p->seg_off, p->unit_base, p->m2, p->group_base, out, out_aux)
     if (wide) { if (small) KQ_LVS(true, 512); else KQ_LVS(true, NB_MAX); }
     else      { if (small) KQ_LVS(false, 512); else KQ_LVS(false, NB_MAX); }
 #undef KQ_LVS
+    mark(h, "k_lv_scatter");
 }
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0;
@@ -1216,6 +1255,8 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     uint8_t* a1 = wide ? p.aux1 : nullptr;
     uint8_t* a2 = wide ? p.aux2 : nullptr;
     p.cfg.filt_lo = h->filt_lo; p.cfg.filt_hi = h->filt_hi;      // KQ_OPT_COUNT_MAP_RANGE
+    marks_reset(h);
+    mark(h, "start");
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
     if (p.two_level) {
         run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
@@ -1223,6 +1264,7 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     } else {
         run_p3(h, &p, p.recs1, a1, AUX_IDX6, p.seg_off);       // bins were the regions themselves
     }
+    mark(h, "k_count_regions");
     HIPC(hipGetLastError());
     return KQ_OK;
 }
