@@ -285,7 +285,6 @@ __device__ __forceinline__ void lane_scan_core(const uint32_t* s_codes, const ui
     const int t = lane_has_work ? tid : 0;
     const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
     const uint64_t wmask = (1ull << k) - 1;
-    const int top = 2 * k - 2;
     const uint32_t c0 = s_codes[t], c1 = s_codes[t + 1], c2 = s_codes[t + 2], c3 = s_codes[t + 3];
     const uint32_t m0 = s_inv[t];
     const uint64_t ms = (uint64_t)s_inv[t + 1] | ((uint64_t)s_inv[t + 2] << 16) | ((uint64_t)s_inv[t + 3] << 32);
@@ -293,19 +292,34 @@ __device__ __forceinline__ void lane_scan_core(const uint32_t* s_codes, const ui
     const uint64_t hi = (uint64_t)c3;
     uint32_t prev = (m0 >> 15) ? 4u : (c0 >> 30);
     const int64_t p0 = (int64_t)(tile * TILE_STARTS) + 16 * t - lo_valid;       // caller position of start 0
+    // Everything that depends on k is shifted into place ONCE (64-bit dynamic shifts are slow);
+    // the 16 steps below then use 32-bit ops with compile-time shifts only:
+    //   ahead / inv_ahead = codes / invalid bits of the bases k..k+15 (the base entering the window at step i),
+    //   inv_lo            = invalid bits of the bases 0..15           (the base leaving it),
+    //   bad               = number of invalid bases inside the current window (rolled: + entering - leaving).
+    const uint32_t ahead = (k == 32) ? (uint32_t)hi : (uint32_t)((lo >> (2 * k)) | (hi << (64 - 2 * k)));
+    const uint32_t inv_ahead = (uint32_t)(ms >> k) & 0xFFFFu;
+    const uint32_t inv_lo = (uint32_t)ms & 0xFFFFu;
+    int bad = __popcll(ms & wmask);
+    const int top = 2 * k - 2;                  // where the entering base lands in fw (wave-uniform)
+    const bool top_hi = top >= 32;
+    const int top_sh = top_hi ? top - 32 : top;
     uint64_t fw = lo & kmask;
     uint64_t rv = revcomp2(fw, k);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const bool valid = lane_has_work && (((ms >> i) & wmask) == 0);
-        const int np = i + k;                                                    // 2..47
-        const uint32_t nraw = (np < 32) ? (uint32_t)(lo >> (2 * np)) & 3u : (uint32_t)(hi >> (2 * (np - 32))) & 3u;
-        const uint32_t next = ((ms >> np) & 1) ? 4u : nraw;
+        const bool valid = lane_has_work && bad == 0;
+        const uint32_t nraw = (ahead >> (2 * i)) & 3u;
+        const uint32_t ninv = (inv_ahead >> i) & 1u;
+        const uint32_t next = ninv ? 4u : nraw;
         if (ALL) f(i, valid, (uint64_t)(p0 + i), fw, rv, prev, next);
         else if (valid) f(i, true, (uint64_t)(p0 + i), fw, rv, prev, next);
-        prev = ((ms >> i) & 1) ? 4u : ((uint32_t)fw & 3u);
-        fw = (fw >> 2) | ((uint64_t)nraw << top);
-        rv = ((rv << 2) | (uint64_t)(3u - nraw)) & kmask;
+        const uint32_t pinv = (inv_lo >> i) & 1u;
+        prev = pinv ? 4u : ((uint32_t)fw & 3u);
+        bad += (int)ninv - (int)pinv;
+        const uint32_t add = nraw << top_sh;
+        fw = (fw >> 2) | (top_hi ? ((uint64_t)add << 32) : (uint64_t)add);       // fw' = fw >> 2 | b[i+k] << (2k-2)
+        rv = ((rv << 2) | (uint64_t)(3u - nraw)) & kmask;                         // rv' = (rv << 2 | 3 - b[i+k]) & mask
     }
 }
 
