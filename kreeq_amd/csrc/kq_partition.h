@@ -119,10 +119,18 @@ __device__ __forceinline__ void ms_scan(S& s, uint32_t nb) {
 // land contiguously at the cursor.  All threads of the block must call it.  nb < NB_MAX.
 // THREADS x ITEMS == MS_TILE records per round (256 x 16 for the tile scanner, 512 x 8 where the
 // records come from memory: twice the waves over the same LDS footprint hides more latency).
-template <bool WIDE, int THREADS = MS_THREADS, int ITEMS = MS_ITEMS, class S>
+// Stores and loads share the vmcnt counter on gfx9 and complete out of order with respect to each
+// other, so a prefetched load that is first USED after this function's stores costs an
+// s_waitcnt vmcnt(0) that also drains the stores.  `landed(x)` marks a register as used (the compiler
+// puts the wait for its load there); callers pass a `pre_store` hook that applies it to their
+// prefetch registers, so the wait sits in front of the stores, where the data has long arrived.
+__device__ __forceinline__ void landed(uint32_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void landed(uint64_t& v) { asm volatile("" : "+v"(v)); }
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <bool WIDE, int THREADS = MS_THREADS, int ITEMS = MS_ITEMS, class S, class F = NoHook>
 __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITEMS], const uint32_t (&aux)[ITEMS],
                                                  const uint32_t (&bin)[ITEMS], uint32_t nb,
-                                                 uint64_t* __restrict__ out, uint8_t* __restrict__ out_aux) {
+                                                 uint64_t* __restrict__ out, uint8_t* __restrict__ out_aux, F pre_store = F()) {
     const int tid = threadIdx.x;
     for (uint32_t b = tid; b <= nb; b += THREADS) s.hist[b] = 0;
     __syncthreads();
@@ -153,6 +161,7 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
         cg[it] = s.gbase[cb[it]] + (j - s.loff[cb[it]]);
         cv[it] = s.stage[j < MS_TILE ? j : 0];
     }
+    pre_store();
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t j = tid + it * THREADS;

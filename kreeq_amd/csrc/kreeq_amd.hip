@@ -191,7 +191,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __re
             }
             bin[i] = valid ? p1_bin(cfg, key) : cfg.n_coarse;
         });
-        block_multisplit<WIDE>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux);   // ends with a barrier
+        block_multisplit<WIDE>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux,
+                               [&] { landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w); });   // ends with a barrier
     }
 }
 
@@ -227,8 +228,18 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
         const uint64_t hi = lo + P2_UNIT < seg_off[b + 1] ? lo + P2_UNIT : seg_off[b + 1];
         for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) s_hist[i] = 0;
         __syncthreads();
-        for (uint64_t i = lo + threadIdx.x; i < hi; i += MS_THREADS)
-            atomicAdd(&s_hist[level_bin(lv, b, region_id(WIDE ? recs[i] : rec_key(recs[i]), lv.n_regions))], 1u);
+        // 8 records per lane in flight, loaded unconditionally (index clamped): a load inside a branch per
+        // iteration costs a full memory latency per record (s_waitcnt vmcnt(0) right behind it)
+        const uint64_t last = hi - 1;                                   // a unit is never empty
+        for (uint64_t base = lo; base < hi; base += 8ull * MS_THREADS) {
+            uint64_t r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = recs[min(base + (uint64_t)j * MS_THREADS + threadIdx.x, last)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi)
+                    atomicAdd(&s_hist[level_bin(lv, b, region_id(WIDE ? r[j] : rec_key(r[j]), lv.n_regions))], 1u);
+        }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) m2[u * lv.nb + i] = s_hist[i];
         __syncthreads();
@@ -274,13 +285,16 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(const uint64_t* __res
         for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS) s.gbase[i] = group_base[(uint64_t)b * nb + i] + m2[u * nb + i];
         __syncthreads();
         // software pipeline: the next round's records are loaded before this round is split
+        // (loads are unconditional, index clamped to the unit: a branch around a load makes the compiler
+        // drain ALL outstanding loads -- the prefetch included -- at the first use)
         uint64_t nxt[LV_ITEMS];
         uint32_t nxt_aux[LV_ITEMS];
+        const uint64_t last = hi - 1;                                   // a unit is never empty
 #pragma unroll
         for (int j = 0; j < LV_ITEMS; ++j) {
-            const uint64_t i = lo + (uint64_t)j * LV_THREADS + threadIdx.x;
-            nxt[j] = i < hi ? recs[i] : 0;
-            nxt_aux[j] = (WIDE && i < hi) ? recs_aux[i] : 0;
+            const uint64_t i = min(lo + (uint64_t)j * LV_THREADS + threadIdx.x, last);
+            nxt[j] = recs[i];
+            nxt_aux[j] = WIDE ? recs_aux[i] : 0;
         }
         for (uint64_t pos = lo; pos < hi; pos += MS_TILE) {
             uint64_t rec[LV_ITEMS];
@@ -294,11 +308,14 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(const uint64_t* __res
             }
 #pragma unroll
             for (int j = 0; j < LV_ITEMS; ++j) {
-                const uint64_t i = pos + MS_TILE + (uint64_t)j * LV_THREADS + threadIdx.x;
-                nxt[j] = i < hi ? recs[i] : 0;
-                nxt_aux[j] = (WIDE && i < hi) ? recs_aux[i] : 0;
+                const uint64_t i = min(pos + MS_TILE + (uint64_t)j * LV_THREADS + threadIdx.x, last);
+                nxt[j] = recs[i];
+                nxt_aux[j] = WIDE ? recs_aux[i] : 0;
             }
-            block_multisplit<WIDE, LV_THREADS, LV_ITEMS>(s, rec, aux, bin, nb, out, out_aux);
+            block_multisplit<WIDE, LV_THREADS, LV_ITEMS>(s, rec, aux, bin, nb, out, out_aux, [&] {
+#pragma unroll
+                for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (WIDE) landed(nxt_aux[j]); }
+            });
         }
     }
 }
@@ -342,16 +359,28 @@ __global__ __launch_bounds__(1024) void k_scan_apply(unsigned long long* __restr
 // P3: one workgroup per table region.  The region's slots (REGION_SLOTS x 24 B) are staged in LDS, all
 // records of the region are applied with LDS atomics (same two-tier rule as table_add), and the
 // image is streamed back.  Global atomics only for the rare high-copy tier and the two totals.
-constexpr int P3_THREADS = 1024;        // two 48 KiB images per CU at the full 32 waves: the walk is a chain of dependent LDS round trips per record, so fewer records per lane wins (256 / 512 / 1024 threads: 1146 / 755 / 700 us)
+#ifdef KQ_STAMPS   // diagnostic build only (never shipped): per-phase cycle sums of k_count_regions
+__device__ unsigned long long g_stamps[8];
+#define KQ_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                         __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) atomicAdd(&g_stamps[i], t_ - stamp_last); stamp_last = t_; } while (0)
+extern "C" int kq_debug_stamps(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 64);
+}
+#else
+#define KQ_STAMP(i) do { } while (0)
+#endif
+constexpr int P3_THREADS = 512;        // three 48 KiB images per CU (24 waves): with records double-buffered and groups handed out by ticket, one more region in flight per CU beats 2 x 1024 threads (whole count job 2.64 vs 2.67 ms)
 // Two instantiations share the regions: HOT = false takes the ordinary ones (deep record prefetch, no
 // folding state: fits the 80 VGPRs that let three workgroups share a CU) and appends the skewed ones
 // to hot_list; HOT = true then walks that list with the folding loop.
 template <bool WIDE, bool HOT>
-__global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 8) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
+__global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
                                                               int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty,
                                                               unsigned long long* __restrict__ hot_list /*[0] = count, then region ids*/) {
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
     __shared__ unsigned long long s_new, s_kmers;
+    __shared__ unsigned int s_grp;
     // high-copy tier of this region, aggregated in LDS: a repeat k-mer with millions of instances
     // would otherwise serialise millions of global atomics on one side-table entry
     constexpr int HC_LDS = 64;
@@ -359,6 +388,9 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 8) void k_count_regions(Table
     __shared__ uint32_t s_hccnt[HC_LDS][8];
     const int tid = threadIdx.x;
     const uint64_t n_work = HOT ? hot_list[0] : t.n_regions;
+#ifdef KQ_STAMPS
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     for (uint64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
         const uint64_t r = HOT ? hot_list[1 + w] : w;
         const uint64_t lo = region_base[r], hi = region_base[r + 1];
@@ -381,52 +413,78 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 8) void k_count_regions(Table
         } else {
             for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
         }
-        if (tid == 0) { s_new = 0; s_kmers = 0; }
+        if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = P3_THREADS / 64; }
         __syncthreads();
+        KQ_STAMP(0);                                                    // region_base load + image init/load + barrier
         uint32_t n_new = 0, n_ok = 0;
-        // apply `cnt` instances of `key` with edge counts e[0..7] (each <= cnt)
-        auto apply = [&](uint64_t key, const uint32_t (&e)[8], uint32_t cnt) {
-            const uint32_t off = (uint32_t)table_hash(key) & (REGION_SLOTS - 1);
-            uint64_t* slot = nullptr;
+        // Slot of `key` in the LDS image (word index), claiming an empty one if needed; REGION_SLOTS*3 = not found.
+        // The image is read with workgroup-scope relaxed atomic loads on the __shared__ array itself: a
+        // volatile access through a generic pointer compiles to flat_load + s_waitcnt vmcnt(0), which also
+        // drains the record prefetches on every probe.
+        auto find_slot = [&](uint64_t key) -> uint32_t {
+            const uint32_t off = (uint32_t)table_hash(key);
             for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
-                uint64_t* s = s_img + 3 * ((off + probe) & (REGION_SLOTS - 1));
-                uint64_t cur = *(volatile uint64_t*)s;
+                const uint32_t w = 3u * ((off + probe) & (REGION_SLOTS - 1));
+                uint64_t cur = __hip_atomic_load(&s_img[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == EMPTY_KEY) {
-                    cur = atomicCAS((unsigned long long*)s, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-                    if (cur == EMPTY_KEY) { ++n_new; slot = s; break; }
+                    cur = atomicCAS((unsigned long long*)&s_img[w], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                    if (cur == EMPTY_KEY) { ++n_new; return w; }
                 }
-                if (cur == key) { slot = s; break; }
+                if (cur == key) return w;
             }
-            if (!slot) { atomicOr(&t.st->err_table_full, 1u); return; }
-            n_ok += cnt;
-            const uint64_t old = atomicAdd((unsigned long long*)&slot[2], (unsigned long long)cnt);
-            uint32_t any = 0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) any |= e[w];
-            if (!any) return;
-            if (old + cnt <= LOW_TIER_MAX) {                        // every e[w] <= cnt <= 254: fits the u8 lanes
-                uint64_t pack = 0;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) pack |= (uint64_t)e[w] << (8 * w);
-                atomicAdd((unsigned long long*)&slot[1], (unsigned long long)pack);
-                return;
-            }
+            atomicOr(&t.st->err_table_full, 1u);
+            return REGION_SLOTS * 3;
+        };
+        // edge counts that no longer fit the u8 lanes: the region's LDS high-copy aggregation, global beyond 64 k-mers
+        auto add_wide = [&](uint64_t key, const uint32_t (&e)[8]) {
             int hslot = -1;
             uint32_t hp = (uint32_t)(table_hash(key) >> 40) & (HC_LDS - 1);
             for (int probe = 0; probe < HC_LDS; ++probe, hp = (hp + 1) & (HC_LDS - 1)) {
-                uint64_t cur = *(volatile uint64_t*)&s_hckey[hp];
+                uint64_t cur = __hip_atomic_load(&s_hckey[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == EMPTY_KEY) cur = atomicCAS((unsigned long long*)&s_hckey[hp], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
                 if (cur == EMPTY_KEY || cur == key) { hslot = (int)hp; break; }
             }
             if (hslot >= 0) {
 #pragma unroll
                 for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd(&s_hccnt[hslot][w], e[w]);
-            } else {                                                // more than 64 high-copy k-mers in one region: go global
+            } else {
                 HcSlot* hs = hc_upsert(t, key);
                 if (!hs) { atomicOr(&t.st->err_hc_full, 1u); return; }
 #pragma unroll
                 for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd((unsigned long long*)&hs->cnt[w], (unsigned long long)e[w]);
             }
+        };
+        // one record: `pack` holds its (at most two) edge bits, one per byte lane
+        auto apply1 = [&](uint64_t key, uint64_t pack) {
+            const uint32_t w = find_slot(key);
+            if (w == REGION_SLOTS * 3) return;
+            ++n_ok;
+            const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], 1ull);
+            if (!pack) return;
+            if (old < LOW_TIER_MAX) { atomicAdd((unsigned long long*)&s_img[w + 1], (unsigned long long)pack); return; }
+            uint32_t e1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e1[q] = (uint32_t)(pack >> (8 * q)) & 1u;
+            add_wide(key, e1);
+        };
+        // `cnt` folded instances of `key` with edge counts e[0..7] (each <= cnt)
+        auto apply = [&](uint64_t key, const uint32_t (&e)[8], uint32_t cnt) {
+            const uint32_t w = find_slot(key);
+            if (w == REGION_SLOTS * 3) return;
+            n_ok += cnt;
+            const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], (unsigned long long)cnt);
+            uint32_t any = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) any |= e[q];
+            if (!any) return;
+            if (old + cnt <= LOW_TIER_MAX) {                        // every e[q] <= cnt <= 254: fits the u8 lanes
+                uint64_t pack = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pack |= (uint64_t)e[q] << (8 * q);
+                atomicAdd((unsigned long long*)&s_img[w + 1], (unsigned long long)pack);
+                return;
+            }
+            add_wide(key, e);
         };
         // Hot k-mers (repeats, homopolymers) put most lanes of a wave on ONE slot, batch after batch.
         // Lanes that share the first active lane's key are folded into a per-wave accumulator kept in
@@ -436,29 +494,48 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 8) void k_count_regions(Table
         bool have_acc = false;
         uint64_t acc_key = 0;
         uint32_t acc_cnt = 0, acc_e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        // records are prefetched PF iterations ahead: the walk must not pay a global-load latency per
-        // iteration (measured: with 2 in flight the kernel waited on record loads most of the time)
+        // Records are double-buffered in registers: the loads of the NEXT group of PF records per lane are
+        // issued (unconditionally, index clamped: no branch around them) before the current group is
+        // walked, so the only wait sits at the top of an iteration on loads that had a whole group's walk
+        // to land.  (A conditional load per record made the compiler wait vmcnt(0) right after issuing
+        // the next prefetch: a full HBM latency per record, ~4k cycles.)
         constexpr int PF = 2;
-        uint64_t pf_rec[PF];
-        uint32_t pf_aux[PF];
+        uint64_t nxt_rec[PF];
+        uint32_t nxt_aux[PF];
+        const uint64_t last = hi - 1;                                  // hi > lo here
+        // groups of PF*64 records are handed to waves from an LDS ticket: waves that hit long probe
+        // chains or contended slots take fewer groups, so all waves reach the barrier together
+        constexpr uint64_t GRP = 64ull * PF;
+        const uint32_t lane = tid & 63;
+        uint32_t g_cur = tid >> 6;
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
-            const uint64_t j = lo + (uint64_t)q * P3_THREADS + tid;
-            pf_rec[q] = j < hi ? recs[j] : 0ull;
-            pf_aux[q] = (WIDE && j < hi) ? recs_aux[j] : 0u;
+            const uint64_t j = min(lo + g_cur * GRP + (uint64_t)q * 64 + lane, last);
+            nxt_rec[q] = recs[j];
+            nxt_aux[q] = WIDE ? recs_aux[j] : 0u;
         }
-        for (uint64_t base = lo; base < hi; base += (uint64_t)PF * P3_THREADS) {   // wave-uniform trip count
+        while (lo + g_cur * GRP < hi) {                                 // wave-uniform
+          uint64_t cur_rec[PF];
+          uint32_t cur_aux[PF];
+#pragma unroll
+          for (int q = 0; q < PF; ++q) { cur_rec[q] = nxt_rec[q]; cur_aux[q] = nxt_aux[q]; }
+          uint32_t g_nxt = 0;
+          if (lane == 0) g_nxt = atomicAdd(&s_grp, 1u);
+          g_nxt = __builtin_amdgcn_readfirstlane(g_nxt);
 #pragma unroll
           for (int q = 0; q < PF; ++q) {
-            const uint64_t i = base + (uint64_t)q * P3_THREADS + tid;
+            const uint64_t j = min(lo + g_nxt * GRP + (uint64_t)q * 64 + lane, last);
+            nxt_rec[q] = recs[j];
+            nxt_aux[q] = WIDE ? recs_aux[j] : 0u;
+          }
+          const uint64_t base = lo + g_cur * GRP;
+          g_cur = g_nxt;
+#pragma unroll
+          for (int q = 0; q < PF; ++q) {
+            const uint64_t i = base + (uint64_t)q * 64 + lane;
             bool active = i < hi;
-            const uint64_t rec = pf_rec[q];
-            const uint32_t aux = pf_aux[q];
-            {
-                const uint64_t j = i + (uint64_t)PF * P3_THREADS;
-                pf_rec[q] = j < hi ? recs[j] : 0ull;
-                pf_aux[q] = (WIDE && j < hi) ? recs_aux[j] : 0u;
-            }
+            const uint64_t rec = cur_rec[q];
+            const uint32_t aux = cur_aux[q];
             uint64_t key = 0, pack = 0;
             if (active) {
                 key = WIDE ? rec : rec_key(rec);
@@ -489,17 +566,13 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 8) void k_count_regions(Table
                     if (in_grp) active = false;
                 }
             }
-            if (active) {
-                uint32_t e1[8];
-#pragma unroll
-                for (int w = 0; w < 8; ++w) e1[w] = (uint32_t)(pack >> (8 * w)) & 1u;
-                apply(key, e1, 1u);
-            }
+            if (active) apply1(key, pack);
           }
         }
         if (have_acc && (tid & 63) == 0) apply(acc_key, acc_e, acc_cnt);
         };
         run(std::integral_constant<bool, HOT>{});
+        KQ_STAMP(1);                                                    // record walk
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { n_new += __shfl_down(n_new, o, 64); n_ok += __shfl_down(n_ok, o, 64); }
         if ((tid & 63) == 0) { if (n_new) atomicAdd(&s_new, (unsigned long long)n_new); if (n_ok) atomicAdd(&s_kmers, (unsigned long long)n_ok); }
@@ -512,12 +585,15 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 8) void k_count_regions(Table
                 for (int e = 0; e < 8; ++e) if (s_hccnt[tid][e]) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)s_hccnt[tid][e]);
             }
         }
+        KQ_STAMP(2);                                                    // barrier (slowest wave) + high-copy flush
         for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) gimg[i] = limg[i];
+        KQ_STAMP(3);                                                    // image store issue
         if (tid == 0) {
             if (s_new) atomicAdd(&t.st->slots_used, s_new);
             if (s_kmers) atomicAdd(&t.st->kmers_added, s_kmers);
         }
         __syncthreads();
+        KQ_STAMP(4);                                                    // final barrier
     }
 }
 
