@@ -394,7 +394,16 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
     for (uint64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
         const uint64_t r = HOT ? hot_list[1 + w] : w;
         const uint64_t lo = region_base[r], hi = region_base[r + 1];
-        if (lo == hi) continue;                                         // block-uniform
+        if (lo == hi) {                                                 // block-uniform
+            if (!HOT && table_is_empty == 2) {    // lazy kq_clear: this launch initialises every region, also the ones without records
+                ulonglong2* g2 = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
+                for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) {
+                    const int w = 2 * i;
+                    g2[i] = make_ulonglong2(w % 3 == 0 ? EMPTY_KEY : 0ull, (w + 1) % 3 == 0 ? EMPTY_KEY : 0ull);
+                }
+            }
+            continue;
+        }
         // folding costs a ballot + shuffle per iteration: only regions that receive far more records than
         // they have slots (skew, or very deep coverage) take that path, in the second launch
         if (!HOT && hi - lo > 32ull * REGION_SLOTS) {
@@ -866,6 +875,7 @@ struct kq_handle {
     uint64_t kmers_bound = 0;        // upper bound of instances inserted (sizing the side table)
     uint64_t used_bound = 0;         // upper bound of occupied slots (skips the state read-back)
     bool table_empty = true;         // nothing inserted since kq_create / kq_clear
+    bool slots_dirty = false;        // the slot array is logically empty but its memory is not initialised yet (lazy clear)
     bool trust_capacity = false;     // KQ_OPT_TRUST_CAPACITY: capacity_hint bounds the distinct k-mers
     int count_path = 0;              // KQ_OPT_COUNT_PATH: 0 auto, 1 direct (global atomics), 2 partitioned
     uint64_t slice_kmers = 1ull << 28;   // KQ_OPT_SLICE_KMERS
@@ -900,6 +910,12 @@ static int ensure_buf(void** p, size_t* have, size_t need) {
 static void clear_words(kq_handle* h, void* p, uint32_t words_per_slot, uint64_t n_slots) {
     const uint64_t n_pairs = n_slots * words_per_slot / 2;      // both table sizes make this exact
     hipLaunchKernelGGL(k_clear_slots, dim3(grid_for(h, n_pairs, 256)), dim3(256), 0, h->stream, (ulonglong2*)p, words_per_slot, n_pairs);
+}
+// lazy kq_clear: give the slot array its empty image now (every table user except the partitioned count)
+static void materialize(kq_handle* h) {
+    if (!h->slots_dirty) return;
+    clear_words(h, h->slots, 3, h->n_slots());
+    h->slots_dirty = false;
 }
 static int alloc_main(kq_handle* h, uint64_t n_regions, Slot** out) {
     Slot* p = nullptr;
@@ -945,7 +961,8 @@ static int grow_main(kq_handle* h, uint64_t need_slots) {
                                              (unsigned long long)want) : rc;
     Slot* old = h->slots; const uint64_t n_old = h->n_slots();
     h->slots = fresh; h->n_regions = new_regions;
-    hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old, n_old);
+    if (h->slots_dirty) h->slots_dirty = false;     // lazily cleared table: nothing to move, and the fresh array is clean
+    else hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old, n_old);
     HIPC(hipStreamSynchronize(h->stream));
     HIPC(hipFree(old));
     return KQ_OK;
@@ -1107,7 +1124,7 @@ void kq_destroy(kq_handle* h) {
 int kq_clear(kq_handle* h) {
     if (!h) return fail(KQ_ERR_INVALID, "null handle");
     HIPC(hipSetDevice(h->device));
-    clear_words(h, h->slots, 3, h->n_slots());
+    h->slots_dirty = true;           // the 24 B/slot clear is folded into the next partitioned count (k_count_regions writes every region); anything else materialises it first
     clear_words(h, h->hc, 9, h->hc_cap);
     HIPC(hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream));
     h->kmers_bound = 0;
@@ -1311,7 +1328,7 @@ static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint
     unsigned long long* hot = p->hot;
     (void)hipMemsetAsync(hot, 0, 8, h->stream);
     const dim3 grid((unsigned)std::min<uint64_t>(p->R, 1u << 30)), grid_hot(h->n_cu), block(P3_THREADS);   // one workgroup per region: dispatcher-balanced
-    const int empty = h->table_empty ? 1 : 0;
+    const int empty = h->table_empty ? (h->slots_dirty ? 2 : 1) : 0;       // 2: also write the image of regions without records
     if (sorted_aux) {
         hipLaunchKernelGGL((k_count_regions<true, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
         hipLaunchKernelGGL((k_count_regions<true, true>), grid_hot, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
@@ -1319,6 +1336,7 @@ static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint
         hipLaunchKernelGGL((k_count_regions<false, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
         hipLaunchKernelGGL((k_count_regions<false, true>), grid_hot, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
     }
+    h->slots_dirty = false;          // every region has been written
 }
 
 // partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
@@ -1403,6 +1421,7 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
         h->table_empty = false;
         PartCfg filt; plan_cfg(h, &filt);
         filt.filt_lo = h->filt_lo; filt.filt_hi = h->filt_hi;
+        materialize(h);
         hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, sub_len), 1)), dim3(TILE_THREADS), 0, h->stream,
                            h->view(), ab, lead, sub_len, h->k, er, filt);
         HIPC(hipGetLastError());
@@ -1546,6 +1565,7 @@ int kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d
         return rc;
     }
     h->table_empty = false;
+    materialize(h);
     hipLaunchKernelGGL(k_insert_records, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, h->view(), d_keys, d_edges, n);
     HIPC(hipGetLastError());
     return KQ_OK;
@@ -1578,6 +1598,7 @@ static int run_summary(kq_handle* h, SummaryHost* r) {
     HIPC(hipMemsetAsync(h->scratch, 0, sizeof(SummaryOut) + HIST_SMALL * sizeof(unsigned long long), h->stream));
     SummaryOut init; memset(&init, 0, sizeof init); init.big_cap = big_cap;
     HIPC(hipMemcpyAsync(d_so, &init, sizeof init, hipMemcpyHostToDevice, h->stream));
+    materialize(h);
     hipLaunchKernelGGL(k_summary, dim3(grid_for(h, h->n_slots(), 1024)), dim3(256), 0, h->stream, h->view(), d_so, d_small, d_big);
     r->small.resize(HIST_SMALL);
     HIPC(hipMemcpyAsync(&r->so, d_so, sizeof(SummaryOut), hipMemcpyDeviceToHost, h->stream));
@@ -1638,6 +1659,7 @@ int kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uint
     aligned_view(d_bases, &ab, &lead);
     const uint32_t map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
     const dim3 grid(grid_for(h, n_tiles_of(lead, len), 1));
+    materialize(h);
     if (d_per_base) hipLaunchKernelGGL(k_lookup<true>, grid, dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len, h->k, (uint32_t)h->map_count,
                                        map_mask, (uint32_t)map_lo, (uint32_t)map_hi, cov_cutoff, d_per_base, (unsigned long long*)d_counters);
     else hipLaunchKernelGGL(k_lookup<false>, grid, dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len, h->k, (uint32_t)h->map_count,
@@ -1683,6 +1705,7 @@ int kq_merge(kq_handle* dst, kq_handle* src) {
     if (dst->k != src->k || dst->map_count != src->map_count || dst->device != src->device)
         return fail(KQ_ERR_MISMATCH, "handles differ in k / map_count / device");    // src/input.cpp:136-139
     HIPC(hipSetDevice(dst->device));
+    materialize(src);                                   // on src's stream, before the sync below
     int rc = kq_sync(src);
     if (rc) return rc;
     rc = read_state(src);
@@ -1690,6 +1713,7 @@ int kq_merge(kq_handle* dst, kq_handle* src) {
     rc = reserve(dst, src->st_host->slots_used, src->st_host->kmers_added);
     if (rc) return rc;
     dst->table_empty = false;
+    materialize(dst);
     hipLaunchKernelGGL(k_merge, dim3(grid_for(dst, src->n_slots(), 256)), dim3(256), 0, dst->stream, dst->view(), src->view());
     HIPC(hipGetLastError());
     return kq_sync(dst);
@@ -1714,6 +1738,7 @@ int kq_import(kq_handle* h, const kq_entry* entries, uint64_t n) {
     void* d = nullptr;
     rc = stage_in(h, entries, n * sizeof(kq_entry), &d);
     if (rc) return rc;
+    materialize(h);
     hipLaunchKernelGGL(k_import, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, h->view(), (const kq_entry*)d, n);
     HIPC(hipGetLastError());
     return kq_sync(h);
@@ -1732,6 +1757,7 @@ int kq_export(kq_handle* h, uint16_t map_lo, uint16_t map_hi, kq_entry* out, uin
     if (out && cap) {
         if (hipMalloc((void**)&d_out, cap * sizeof(kq_entry)) != hipSuccess) { (void)hipFree(d_n); return fail(KQ_ERR_NOMEM, "export buffer allocation failed"); }
     }
+    materialize(h);
     hipLaunchKernelGGL(k_export, dim3(grid_for(h, h->n_slots(), 1024)), dim3(256), 0, h->stream, h->view(), (uint32_t)h->map_count,
                        (uint32_t)map_lo, (uint32_t)map_hi, d_out, d_out ? cap : 0, d_n);
     unsigned long long n = 0;

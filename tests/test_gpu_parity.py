@@ -455,6 +455,54 @@ def test_sharded_counter_rccl_world1(kq, O):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("follow", ["partitioned_sparse", "partitioned", "direct", "insert_records", "import", "lookup", "summary", "export",
+                                    "merge_dst", "merge_src", "grow"])
+def test_clear_then_every_operation(kq, O, follow):
+    """kq_clear defers the slot-array clear into the next partitioned count (k_count_regions writes every
+    region, also the ones that receive no record); every other table user must materialise it first.
+    The table is filled with unrelated k-mers before the clear, so stale slots would show."""
+    junk, _ = H.synth_reads(20000, 150, 70000, seed=901, err=0.01)
+    batch, genome = H.synth_reads(6000, 120, 20000, seed=902, err=0.01, n_rate=0.003)
+    tiny = batch[:batch.find(b"\n", 2000)]
+    gpu, cpu = kq.KreeqDB(21, 128, capacity_hint=3_000_000), O.OracleDB(21, 128)
+    gpu.set_option("count_path", "partitioned")
+    gpu.count_batch(junk)
+    gpu.clear()
+    if follow in ("partitioned", "partitioned_sparse", "direct"):
+        b = tiny if follow == "partitioned_sparse" else batch          # sparse: most regions get no record at all
+        gpu.set_option("count_path", "direct" if follow == "direct" else "partitioned")
+        gpu.count_batch(b)
+        cpu.count_batch(b, threads=8)
+    elif follow == "insert_records":
+        keys, edges = kq.KreeqDB(21, 128).emit_records(batch)
+        gpu.insert_records(keys, edges)
+        cpu.count_batch(batch, threads=8)
+    elif follow == "import":
+        cpu.count_batch(batch, threads=8)
+        gpu.import_entries(cpu.export())
+    elif follow == "lookup":
+        cg, _ = gpu.lookup_sequence(genome)
+        cc, _ = cpu.validate_sequence(genome, threads=8)
+        assert np.array_equal(cg, cc)
+    elif follow in ("merge_dst", "merge_src"):
+        other = kq.KreeqDB(21, 128, capacity_hint=3_000_000)
+        other.count_batch(batch)
+        cpu.count_batch(batch, threads=8)
+        if follow == "merge_dst":
+            gpu.merge(other)
+        else:
+            other.merge(gpu)                                            # a cleared source adds nothing
+            gpu = other
+    elif follow == "grow":
+        gpu.set_option("count_path", "direct")
+        big, _ = H.synth_reads(60000, 150, 4_000_000, seed=903, err=0.0)   # more distinct k-mers than the hint: rehash of a lazily cleared table
+        gpu.count_batch(big)
+        cpu.count_batch(big, threads=8)
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(gpu.export(), cpu.export())
+    assert gpu.info()["slots_used"] == cpu.summary()["distinct"]
+
+
 @pytest.mark.parametrize("path,k", [("partitioned", 21), ("direct", 21), ("partitioned", 31)])
 def test_sliced_resident_batch(kq, O, path, k):
     """a resident batch is cut into slices at arbitrary positions (inside reads): every k-mer and
