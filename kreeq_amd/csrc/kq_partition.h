@@ -88,7 +88,18 @@ struct MsShared {
     uint32_t loff[NBC];
     unsigned long long gbase[NBC];
     uint32_t wave_sum[16];
+#ifdef KQ_MS_STAMPS
+    unsigned long long stamp_last;
+    int stamp_on;
+#endif
 };
+#ifdef KQ_MS_STAMPS   // diagnostic build only (never shipped): per-phase cycle sums of the multisplit rounds
+__device__ unsigned long long g_ms_stamps[16];
+#define KQ_MS_STAMP(s, i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+        __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && (s).stamp_on) { atomicAdd(&g_ms_stamps[i], t_ - (s).stamp_last); (s).stamp_last = t_; } } while (0)
+#else
+#define KQ_MS_STAMP(s, i) do { } while (0)
+#endif
 
 // exclusive scan of s.hist[0..nb) into s.loff.  nb <= NBC.
 template <int THREADS, class S>
@@ -132,14 +143,18 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
                                                  const uint32_t (&bin)[ITEMS], uint32_t nb,
                                                  uint64_t* __restrict__ out, uint8_t* __restrict__ out_aux, F pre_store = F()) {
     const int tid = threadIdx.x;
+    KQ_MS_STAMP(s, 0);                            // caller: loads landed, bins computed
     for (uint32_t b = tid; b <= nb; b += THREADS) s.hist[b] = 0;
     __syncthreads();
-    static_assert(THREADS * ITEMS == MS_TILE, "round size");
+    KQ_MS_STAMP(s, 1);                            // zero hist + barrier
+    static_assert(THREADS * ITEMS <= MS_TILE, "round size");
     uint32_t rank[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) rank[i] = atomicAdd(&s.hist[bin[i]], 1u);
     __syncthreads();
+    KQ_MS_STAMP(s, 2);                            // rank atomics + barrier
     ms_scan<THREADS>(s, nb + 1);
+    KQ_MS_STAMP(s, 3);                            // scan (2 barriers)
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t p = s.loff[bin[i]] + rank[i];
@@ -148,6 +163,7 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
         if (WIDE) s.saux[p] = (uint8_t)aux[i];
     }
     __syncthreads();
+    KQ_MS_STAMP(s, 4);                            // stage writes + barrier
     const uint32_t total = s.loff[nb];           // records in front of the discard bin
     // fully unrolled so that the LDS reads of all ITEMS positions are in flight together (a rolled
     // loop is a chain of three dependent LDS round trips per record)
@@ -159,9 +175,11 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t j = tid + it * THREADS;
         cg[it] = s.gbase[cb[it]] + (j - s.loff[cb[it]]);
-        cv[it] = s.stage[j < MS_TILE ? j : 0];
+        cv[it] = s.stage[j];
     }
+    KQ_MS_STAMP(s, 5);                            // copy-out LDS reads
     pre_store();
+    KQ_MS_STAMP(s, 6);                            // prefetch landed
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t j = tid + it * THREADS;
@@ -171,6 +189,7 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
         }
     }
     __syncthreads();
+    KQ_MS_STAMP(s, 7);                            // global stores issued + barrier
     // advance the cursors; the same thread zeroes hist[b] at the start of the next round
     for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] += s.hist[b];
 }

@@ -162,7 +162,7 @@ __global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const un
 }
 // P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
 template <bool WIDE, int NBC>
-__global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+__global__ __launch_bounds__(TILE_THREADS, 3) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
                                                              PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
                                                              uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
     __shared__ uint32_t s_codes[TILE_THREADS];
@@ -172,7 +172,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_scatter(const uint8_t* __re
     const uint64_t n_tiles = n_tiles_of(lead, len);
     const uint64_t cols = (uint64_t)gridDim.x * P1_F;
     for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += MS_THREADS) s.gbase[b] = m1[(uint64_t)b * cols + (uint64_t)blockIdx.x * P1_F];
+#ifdef KQ_MS_STAMPS
+    if (threadIdx.x == 0) s.stamp_on = 0;
+#endif
     uint4 nxt = tile_fetch(ab, lo_valid, hi_valid, blockIdx.x);
+    landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w);         // see k_lv_scatter: keeps the loop header free of a store-draining wait
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         tile_store(nxt, lo_valid, hi_valid, tile, s_codes, s_inv);        // barrier inside (covers the cursor init)
         if (tile + gridDim.x < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + gridDim.x);   // in flight during the split
@@ -268,9 +272,14 @@ __global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, L
     if (lane == 0) group_count[r] = run;
 }
 // pass B: records -> grouped by (segment, bin); private cursors = group_base + unit prefix
-constexpr int LV_THREADS = 512, LV_ITEMS = 8;       // records come from memory: more waves per LDS footprint
+#ifndef KQ_LV_THREADS
+#define KQ_LV_THREADS 512
+#define KQ_LV_ITEMS 8
+#define KQ_LV_OCC 4
+#endif
+constexpr int LV_THREADS = KQ_LV_THREADS, LV_ITEMS = KQ_LV_ITEMS, LV_TILE = LV_THREADS * LV_ITEMS;       // records come from memory: more waves per LDS footprint
 template <bool WIDE, int NBC>
-__global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
+__global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
                                                            const unsigned long long* __restrict__ seg_off,
                                                            const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
                                                            const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out,
@@ -283,6 +292,9 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(const uint64_t* __res
         const uint64_t lo = seg_off[b] + (u - unit_base[b]) * P2_UNIT;
         const uint64_t hi = lo + P2_UNIT < seg_off[b + 1] ? lo + P2_UNIT : seg_off[b + 1];
         for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS) s.gbase[i] = group_base[(uint64_t)b * nb + i] + m2[u * nb + i];
+#ifdef KQ_MS_STAMPS
+        if (threadIdx.x == 0) { s.stamp_on = 1; s.stamp_last = __builtin_amdgcn_s_memtime(); }
+#endif
         __syncthreads();
         // software pipeline: the next round's records are loaded before this round is split
         // (loads are unconditional, index clamped to the unit: a branch around a load makes the compiler
@@ -296,7 +308,11 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(const uint64_t* __res
             nxt[j] = recs[i];
             nxt_aux[j] = WIDE ? recs_aux[i] : 0;
         }
-        for (uint64_t pos = lo; pos < hi; pos += MS_TILE) {
+        // wait for the first round's records HERE: otherwise the loop header inherits "loads pending" from
+        // this path and its s_waitcnt vmcnt(0) also drains the previous round's stores on the back edge
+#pragma unroll
+        for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (WIDE) landed(nxt_aux[j]); }
+        for (uint64_t pos = lo; pos < hi; pos += LV_TILE) {
             uint64_t rec[LV_ITEMS];
             uint32_t aux[LV_ITEMS], bin[LV_ITEMS];
 #pragma unroll
@@ -308,7 +324,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(const uint64_t* __res
             }
 #pragma unroll
             for (int j = 0; j < LV_ITEMS; ++j) {
-                const uint64_t i = min(pos + MS_TILE + (uint64_t)j * LV_THREADS + threadIdx.x, last);
+                const uint64_t i = min(pos + LV_TILE + (uint64_t)j * LV_THREADS + threadIdx.x, last);
                 nxt[j] = recs[i];
                 nxt_aux[j] = WIDE ? recs_aux[i] : 0;
             }
@@ -363,6 +379,14 @@ __global__ __launch_bounds__(1024) void k_scan_apply(unsigned long long* __restr
 __device__ unsigned long long g_stamps[8];
 #define KQ_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
                          __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) atomicAdd(&g_stamps[i], t_ - stamp_last); stamp_last = t_; } while (0)
+#endif
+#ifdef KQ_MS_STAMPS
+extern "C" int kq_debug_ms_stamps(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(kq::g_ms_stamps), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kq::g_ms_stamps), 128);
+}
+#endif
+#ifdef KQ_STAMPS
 extern "C" int kq_debug_stamps(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z); }
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 64);
