@@ -143,10 +143,12 @@ int  kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, in
                              uint64_t* d_keys, uint8_t* d_edges, uint64_t cap,
                              uint64_t* part_counts);
 
-/* Same staging with PACKED 8-byte records (k <= 28): bits 0..2k-1 = key, bits 56..58 / 59..61 = index
- * of the fw / bw edge the instance contributes (0..3, 7 = none; src/graph-builder.cpp:98-110).  One
- * array to exchange instead of two, and the receive side (kq_insert_packed_dev) runs the
- * partitioned, atomic-free count.  d_recs needs room for len - k + 1 records.  Synchronises. */
+/* Same staging with PACKED 8-byte records (k <= 28): bits 0..55 = the library's invertible 56-bit mix
+ * of the canonical key (its table hash; opaque to the caller, identical on every handle with the same
+ * k), bits 56..58 / 59..61 = index of the fw / bw edge the instance contributes (0..3, 7 = none;
+ * src/graph-builder.cpp:98-110).  One array to exchange instead of two, and the receive side
+ * (kq_insert_packed_dev, the only consumer of this format) runs the partitioned, atomic-free count
+ * without hashing again.  d_recs needs room for len - k + 1 records.  Synchronises. */
 int  kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts,
                         uint64_t* d_recs, uint64_t cap, uint64_t* part_counts);
 int  kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n);

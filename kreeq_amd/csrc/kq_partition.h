@@ -35,6 +35,7 @@ struct PartCfg {
     uint32_t map_count;   // mode 1: gfalibs mapCount
     uint32_t map_mask;    // map_count - 1 when it is a power of two, else 0
     uint32_t filt_lo, filt_hi;   // count only k-mers whose map index key % map_count lies in [filt_lo, filt_hi)
+    uint32_t raw_out;     // 1: WIDE records carry the raw key (kq_emit_partitioned_dev), else its table hash
 };
 
 // One level of the record split.  Input records are grouped in n_seg segments (seg_off[0..n_seg]);
@@ -45,6 +46,8 @@ struct PartCfg {
 struct LevelCfg {
     uint64_t n_regions;
     uint32_t n_seg, nb, seg_shift, out_shift;
+    uint32_t in_raw;        // 1: the input records hold raw keys (kq_insert_records): this level mixes them
+    uint32_t mix_wide;      // the table's mix width (k > 28), needed when in_raw
 };
 __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, uint64_t region) {
     return (uint32_t)(region >> lv.out_shift) - (lv.seg_shift >= 32 ? 0u : (b << (lv.seg_shift - lv.out_shift)));
@@ -74,7 +77,13 @@ __device__ __forceinline__ uint64_t rec_edge_pack(uint64_t rec) {
     const uint32_t f = (uint32_t)(rec >> REC_EDGE_SHIFT) & 7u, b = (uint32_t)(rec >> (REC_EDGE_SHIFT + 3)) & 7u;
     return (f < 4 ? 1ull << (8 * f) : 0ull) | (b < 4 ? 1ull << (8 * (4 + b)) : 0ull);
 }
-__device__ __forceinline__ uint64_t region_id(uint64_t key, uint64_t n_regions) { return hash_region(table_hash(key), n_regions); }
+// Records carry the table hash of their k-mer (kq_device.h: an invertible mix), not the key: packed
+// records its 56 significant bits under the two edge indices, WIDE records the left-aligned 64 bits.
+template <bool WIDE>
+__device__ __forceinline__ uint64_t rec_hash(uint64_t rec) { return WIDE ? rec : rec << 8; }     // the shift drops the edge bits
+__device__ __forceinline__ uint64_t rec_pack_hash(uint64_t h, bool is_fw, uint32_t prev, uint32_t next) {
+    return (h >> 8) | ((uint64_t)edge_idx6(is_fw, prev, next) << REC_EDGE_SHIFT);
+}
 
 // LDS of one multisplit workgroup.  NBC = bin capacity (incl. the discard bin): 512 keeps the whole
 // struct at 48 KiB (three workgroups per CU) and covers the usual fan-outs; 2048 (72-76 KiB, two per
@@ -203,12 +212,12 @@ __device__ __forceinline__ uint32_t map_index(uint64_t key, uint32_t map_count, 
     return map_mask ? (uint32_t)key & map_mask : (uint32_t)(key % map_count);                  // src/graph-builder.cpp:95
 }
 // bin of a key in P1, or cfg.n_coarse (the discard bin) when the map-range filter rejects it
-__device__ __forceinline__ uint32_t p1_bin(const PartCfg& cfg, uint64_t key) {
+__device__ __forceinline__ uint32_t p1_bin(const PartCfg& cfg, uint64_t key, uint64_t h) {
     if (cfg.filt_lo != 0 || cfg.filt_hi != cfg.map_count) {
         const uint32_t m = map_index(key, cfg.map_count, cfg.map_mask);
         if (m < cfg.filt_lo || m >= cfg.filt_hi) return cfg.n_coarse;
     }
-    return cfg.mode == 0 ? (uint32_t)(region_id(key, cfg.n_regions) >> cfg.g_shift)
+    return cfg.mode == 0 ? (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift)
                          : owner_part_of(key, cfg.map_count, cfg.map_mask, cfg.n_coarse);
 }
 

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
         tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);         // barrier inside (also covers the zeroing above)
         tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
             if (valid) {
-                const uint32_t b = p1_bin(cfg, fw < rv ? fw : rv);
+                const uint64_t key = fw < rv ? fw : rv;
+                const uint32_t b = p1_bin(cfg, key, table_hash(key, k > PART_MAX_K));
                 if (b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
             }
         });
@@ -162,7 +163,7 @@ __global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const un
 }
 // P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
 template <bool WIDE, int NBC>
-__global__ __launch_bounds__(TILE_THREADS, 3) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+__global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && !WIDE) ? 3 : 2) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
                                                              PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
                                                              uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
     __shared__ uint32_t s_codes[TILE_THREADS];
@@ -185,15 +186,16 @@ __global__ __launch_bounds__(TILE_THREADS, 3) void k_p1_scatter(const uint8_t* _
         tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int i, bool valid, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
             const bool is_fw = fw < rv;
             const uint64_t key = is_fw ? fw : rv;
+            const uint64_t h = table_hash(key, k > PART_MAX_K);             // the only hash of this k-mer on the whole path
             if (WIDE) {
-                rec[i] = key;
+                rec[i] = cfg.raw_out ? key : h;                             // raw keys only for kq_emit_partitioned_dev's caller
                 const uint32_t e = edge_idx6(is_fw, prev, next);
                 aux[i] = aux_fmt == AUX_IDX6 ? e : idx6_to_edge_byte(e);
             } else {
-                rec[i] = rec_pack(key, is_fw, prev, next);
+                rec[i] = rec_pack_hash(h, is_fw, prev, next);
                 aux[i] = 0;
             }
-            bin[i] = valid ? p1_bin(cfg, key) : cfg.n_coarse;
+            bin[i] = valid ? p1_bin(cfg, key, h) : cfg.n_coarse;
         });
         block_multisplit<WIDE>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux,
                                [&] { landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w); });   // ends with a barrier
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi)
-                    atomicAdd(&s_hist[level_bin(lv, b, region_id(WIDE ? r[j] : rec_key(r[j]), lv.n_regions))], 1u);
+                    atomicAdd(&s_hist[level_bin(lv, b, hash_region(lv.in_raw ? table_hash(r[j], lv.mix_wide) : rec_hash<WIDE>(r[j]), lv.n_regions))], 1u);
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) m2[u * lv.nb + i] = s_hist[i];
@@ -318,9 +320,9 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
 #pragma unroll
             for (int j = 0; j < LV_ITEMS; ++j) {
                 const uint64_t i = pos + (uint64_t)j * LV_THREADS + threadIdx.x;
-                rec[j] = nxt[j];
+                rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.mix_wide) : nxt[j];      // raw keys become hashes at the first level
                 aux[j] = nxt_aux[j];
-                bin[j] = i < hi ? level_bin(lv, b, region_id(WIDE ? rec[j] : rec_key(rec[j]), lv.n_regions)) : nb;
+                bin[j] = i < hi ? level_bin(lv, b, hash_region(rec_hash<WIDE>(rec[j]), lv.n_regions)) : nb;
             }
 #pragma unroll
             for (int j = 0; j < LV_ITEMS; ++j) {
@@ -454,8 +456,8 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
         // The image is read with workgroup-scope relaxed atomic loads on the __shared__ array itself: a
         // volatile access through a generic pointer compiles to flat_load + s_waitcnt vmcnt(0), which also
         // drains the record prefetches on every probe.
-        auto find_slot = [&](uint64_t key) -> uint32_t {
-            const uint32_t off = (uint32_t)table_hash(key);
+        auto find_slot = [&](uint64_t key, uint64_t h) -> uint32_t {
+            const uint32_t off = hash_offset(h);
             for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
                 const uint32_t w = 3u * ((off + probe) & (REGION_SLOTS - 1));
                 uint64_t cur = __hip_atomic_load(&s_img[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -469,9 +471,9 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
             return REGION_SLOTS * 3;
         };
         // edge counts that no longer fit the u8 lanes: the region's LDS high-copy aggregation, global beyond 64 k-mers
-        auto add_wide = [&](uint64_t key, const uint32_t (&e)[8]) {
+        auto add_wide = [&](uint64_t key, uint64_t h, const uint32_t (&e)[8]) {
             int hslot = -1;
-            uint32_t hp = (uint32_t)(table_hash(key) >> 40) & (HC_LDS - 1);
+            uint32_t hp = (uint32_t)(h >> 40) & (HC_LDS - 1);
             for (int probe = 0; probe < HC_LDS; ++probe, hp = (hp + 1) & (HC_LDS - 1)) {
                 uint64_t cur = __hip_atomic_load(&s_hckey[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == EMPTY_KEY) cur = atomicCAS((unsigned long long*)&s_hckey[hp], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
@@ -488,8 +490,8 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
             }
         };
         // one record: `pack` holds its (at most two) edge bits, one per byte lane
-        auto apply1 = [&](uint64_t key, uint64_t pack) {
-            const uint32_t w = find_slot(key);
+        auto apply1 = [&](uint64_t key, uint64_t h, uint64_t pack) {
+            const uint32_t w = find_slot(key, h);
             if (w == REGION_SLOTS * 3) return;
             ++n_ok;
             const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], 1ull);
@@ -498,11 +500,12 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
             uint32_t e1[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) e1[q] = (uint32_t)(pack >> (8 * q)) & 1u;
-            add_wide(key, e1);
+            add_wide(key, h, e1);
         };
         // `cnt` folded instances of `key` with edge counts e[0..7] (each <= cnt)
         auto apply = [&](uint64_t key, const uint32_t (&e)[8], uint32_t cnt) {
-            const uint32_t w = find_slot(key);
+            const uint64_t h = table_hash(key, t.wide);
+            const uint32_t w = find_slot(key, h);
             if (w == REGION_SLOTS * 3) return;
             n_ok += cnt;
             const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], (unsigned long long)cnt);
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
                 atomicAdd((unsigned long long*)&s_img[w + 1], (unsigned long long)pack);
                 return;
             }
-            add_wide(key, e);
+            add_wide(key, h, e);
         };
         // Hot k-mers (repeats, homopolymers) put most lanes of a wave on ONE slot, batch after batch.
         // Lanes that share the first active lane's key are folded into a per-wave accumulator kept in
@@ -570,8 +573,9 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
             const uint64_t rec = cur_rec[q];
             const uint32_t aux = cur_aux[q];
             uint64_t key = 0, pack = 0;
+            const uint64_t h = rec_hash<WIDE>(rec);
             if (active) {
-                key = WIDE ? rec : rec_key(rec);
+                key = key_of_hash(h, t.wide);                                   // the mix is a bijection: no key in the record
                 pack = WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
             }
             const uint64_t act = FOLD ? __ballot(active) : 0ull;
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
                     if (in_grp) active = false;
                 }
             }
-            if (active) apply1(key, pack);
+            if (active) apply1(key, h, pack);
           }
         }
         if (have_acc && (tid & 63) == 0) apply(acc_key, acc_e, acc_cnt);
@@ -908,7 +912,7 @@ struct kq_handle {
     std::vector<std::pair<const char*, hipEvent_t>> marks;
     void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
 
-    TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; return v; }
+    TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; v.wide = k > 28 ? 1u : 0u; return v; }
     uint64_t n_slots() const { return n_regions << REGION_SHIFT; }
 };
 
@@ -1247,6 +1251,7 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg) {
     cfg->mode = 0; cfg->map_count = (uint32_t)h->map_count;
     cfg->map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
     cfg->filt_lo = 0; cfg->filt_hi = (uint32_t)h->map_count;
+    cfg->raw_out = 0;
 }
 // carve the scratch buffer for a batch of at most n_max records; n_tiles = 0 when the input is records
 static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins) {
@@ -1340,11 +1345,11 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     mark(h, "k_lv_scatter");
 }
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
-    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0;
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.mix_wide = 0;
     return lv;
 }
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
-    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift;
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.mix_wide = 0;
     return lv;
 }
 static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint8_t* sorted_aux, int aux_fmt, const unsigned long long* base) {
@@ -1388,14 +1393,17 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
 }
 // partitioned count of n records already on the device (multi-GPU receive side, kq_insert_records_dev).
 // d_aux == nullptr: packed 8-byte records; else WIDE records with d_aux in `aux_fmt`.
-static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const uint8_t* d_aux, int aux_fmt, uint64_t n) {
+// `raw`: d_recs holds raw keys (kq_insert_records); otherwise the records of kq_emit_packed_dev (table hashes)
+static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const uint8_t* d_aux, int aux_fmt, uint64_t n, bool raw) {
     PartPlan p;
     int rc = plan_alloc(h, &p, n, 0, 1);
     if (rc) return rc;
     uint8_t* a1 = d_aux ? p.aux1 : nullptr;
     uint8_t* a2 = d_aux ? p.aux2 : nullptr;
     hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, h->stream, p.seg_off, 0ull, (unsigned long long)n);
-    run_level(h, &p, level_flat_to_coarse(p.cfg), d_recs, d_aux, p.recs1, a1);        // group_base = coarse offsets
+    LevelCfg first = level_flat_to_coarse(p.cfg);
+    first.in_raw = raw ? 1 : 0; first.mix_wide = h->k > 28 ? 1 : 0;
+    run_level(h, &p, first, d_recs, d_aux, p.recs1, a1);        // group_base = coarse offsets
     if (p.two_level) {
         // the coarse offsets become the segment table of the next level
         HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)(p.cfg.n_coarse + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -1531,6 +1539,7 @@ int kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, int
     if (rc) return rc;
     PartCfg cfg = p.cfg;
     cfg.mode = 1; cfg.n_coarse = (uint32_t)n_parts;
+    cfg.raw_out = 1;
     run_p1(h, &p, cfg, ab, lead, len, EmitRange{0, ~0ull}, d_keys, d_edges, AUX_EDGE_BYTE);      // WIDE records: key + reference edge byte
     std::vector<unsigned long long> off((size_t)n_parts + 1);
     HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
@@ -1572,7 +1581,7 @@ int kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n) {
     int rc = reserve(h, n, n);
     if (rc) return rc;
     if (h->n_regions > (1ull << 20)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
-    rc = count_partitioned_records(h, d_recs, nullptr, AUX_IDX6, n);
+    rc = count_partitioned_records(h, d_recs, nullptr, AUX_IDX6, n, false);
     h->table_empty = false;
     return rc;
 }
@@ -1584,7 +1593,7 @@ int kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d
     int rc = reserve(h, n, n);
     if (rc) return rc;
     if ((h->count_path == 2 || (h->count_path == 0 && n >= (1u << 20))) && h->n_regions <= (1ull << 20)) {   // WIDE records: key + reference edge byte
-        rc = count_partitioned_records(h, d_keys, d_edges, AUX_EDGE_BYTE, n);
+        rc = count_partitioned_records(h, d_keys, d_edges, AUX_EDGE_BYTE, n, true);
         h->table_empty = false;
         return rc;
     }

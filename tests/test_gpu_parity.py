@@ -359,7 +359,15 @@ def test_partitioned_wide_records(kq, O, k, hint):
 def _unpack_records(recs):
     """packed 8-byte records (include/kreeq_amd.h: kq_emit_packed_dev) -> (key, reference edge byte)"""
     recs = recs.astype(np.uint64)
-    key = recs & np.uint64((1 << 56) - 1)
+    # bits 0..55 = the invertible 56-bit mix of the key (kq_device.h table_hash): undo it
+    M56, MUL = (1 << 56) - 1, 0x9E3779B97F4A7C15
+    inv = pow(MUL, -1, 1 << 64) & M56
+    x = recs & np.uint64(M56)
+    x = x ^ (x >> np.uint64(28))
+    lo, hi = x & np.uint64(0xFFFFFFF), x >> np.uint64(28)                   # 56-bit modular product from 28-bit limbs
+    il, ih = np.uint64(inv & 0xFFFFFFF), np.uint64(inv >> 28)
+    x = (lo * il + (((lo * ih + hi * il) & np.uint64(0xFFFFFFF)) << np.uint64(28))) & np.uint64(M56)
+    key = x ^ (x >> np.uint64(28))
     f = ((recs >> np.uint64(56)) & np.uint64(7)).astype(np.int64)
     b = ((recs >> np.uint64(59)) & np.uint64(7)).astype(np.int64)
     edge = np.where(f < 4, 1 << (7 - np.minimum(f, 3)), 0) | np.where(b < 4, 1 << (7 - (4 + np.minimum(b, 3))), 0)
