@@ -43,16 +43,17 @@ struct TableView {
     HcSlot* hc;
     uint64_t hc_mask;       // capacity - 1
     DevState* st;
-    uint32_t wide;          // k > 28: 64-bit mix (else the 56-bit one that fits a packed record)
+    uint32_t k;             // k-mer length: the table hash mixes exactly 2k bits
 };
 
-// Table hash = an INVERTIBLE mix of the key (one xorshift-multiply-xorshift round: a bijection on 56
-// bits for k <= 28, on 64 bits above), returned left-aligned in 64 bits.  Region = top 32 bits scaled
-// to n_regions (< 2^32), in-region offset = bits 8..18.  Because the mix is a bijection, the records
-// of the partitioned count path carry the mixed value instead of the key (the hash is computed once,
-// in the tile scanner; every later stage reads region / offset bits straight from the record) and
-// k_count_regions recovers the key with the inverse (`key_of_hash`).  Uniformity on k-mer sets is
-// indistinguishable from murmur3's finaliser (region occupancy sd = Poisson).
+// Table hash = an INVERTIBLE mix of the key: one xorshift-multiply-xorshift round that is a bijection
+// on the 2k bits a canonical key occupies, returned left-aligned in 64 bits.  Region = top 32 bits
+// scaled to n_regions (< 2^32), in-region offset = the low 11 bits of the mixed value.  Because the mix
+// is a bijection, the records of the partitioned count path carry the mixed value instead of the key
+// (the hash is computed once, in the tile scanner; every later stage reads region / offset bits straight
+// from the record, and a stage may drop the bits its position already implies) and k_count_regions
+// recovers the key with the inverse (`key_of_hash`).  Region occupancy on k-mer sets is Poisson-like,
+// indistinguishable from murmur3's finaliser.
 constexpr uint64_t MIX_MUL = 0x9E3779B97F4A7C15ull;
 constexpr uint64_t mul_inverse(uint64_t a) {                 // a odd: Newton iteration doubles the correct bits
     uint64_t x = a;
@@ -61,30 +62,20 @@ constexpr uint64_t mul_inverse(uint64_t a) {                 // a odd: Newton it
 }
 constexpr uint64_t MIX_INV = mul_inverse(MIX_MUL);
 static_assert(MIX_MUL * MIX_INV == 1ull, "inverse");
-constexpr uint64_t MASK56 = (1ull << 56) - 1;
-__device__ __forceinline__ uint64_t table_hash(uint64_t key, bool wide) {
-    if (wide) {
-        uint64_t x = key ^ (key >> 32);
-        x *= MIX_MUL;
-        return x ^ (x >> 32);
-    }
-    uint64_t x = key ^ (key >> 28);                          // key < 2^56
-    x = (x * MIX_MUL) & MASK56;
-    return (x ^ (x >> 28)) << 8;
+__device__ __forceinline__ uint64_t table_hash(uint64_t key, uint32_t k) {      // key < 4^k, 1 <= k <= 32
+    const uint32_t pad = 64 - 2 * k;
+    uint64_t x = key ^ (key >> k);                           // shift >= half the width: self-inverse
+    x = (x * MIX_MUL) << pad;                                // left-aligned product mod 4^k
+    return x ^ ((x >> k) & (~0ull << pad));
 }
-__device__ __forceinline__ uint64_t key_of_hash(uint64_t h, bool wide) {
-    if (wide) {
-        uint64_t x = h ^ (h >> 32);
-        x *= MIX_INV;
-        return x ^ (x >> 32);
-    }
-    uint64_t x = h >> 8;
-    x ^= x >> 28;
-    x = (x * MIX_INV) & MASK56;
-    return x ^ (x >> 28);
+__device__ __forceinline__ uint64_t key_of_hash(uint64_t h, uint32_t k) {
+    const uint32_t pad = 64 - 2 * k;
+    uint64_t x = (h ^ ((h >> k) & (~0ull << pad))) >> pad;
+    x = ((x * MIX_INV) << pad) >> pad;
+    return x ^ (x >> k);
 }
 __device__ __forceinline__ uint64_t hash_region(uint64_t h, uint64_t n_regions) { return __umulhi((uint32_t)(h >> 32), (uint32_t)n_regions); }
-__device__ __forceinline__ uint32_t hash_offset(uint64_t h) { return (uint32_t)(h >> 8) & (REGION_SLOTS - 1); }
+__device__ __forceinline__ uint32_t hash_offset(uint64_t h, uint32_t k) { return (uint32_t)(h >> (64 - 2 * k)) & (REGION_SLOTS - 1); }
 
 __device__ __forceinline__ uint64_t mix64(uint64_t h) {
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
@@ -139,9 +130,9 @@ __device__ __forceinline__ Slot* region_of(const TableView& t, uint64_t h) {
 
 // find-or-insert; returns nullptr when the region is full. *inserted = 1 for a new key.
 __device__ __forceinline__ Slot* table_upsert(const TableView& t, uint64_t key, uint32_t* inserted) {
-    const uint64_t h = table_hash(key, t.wide);
+    const uint64_t h = table_hash(key, t.k);
     Slot* base = region_of(t, h);
-    uint32_t off = hash_offset(h);
+    uint32_t off = hash_offset(h, t.k);
     for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
         Slot* s = base + ((off + probe) & (REGION_SLOTS - 1));
         uint64_t cur = ld_relaxed(&s->key);
@@ -155,9 +146,9 @@ __device__ __forceinline__ Slot* table_upsert(const TableView& t, uint64_t key, 
 }
 
 __device__ __forceinline__ const Slot* table_find(const TableView& t, uint64_t key) {
-    const uint64_t h = table_hash(key, t.wide);
+    const uint64_t h = table_hash(key, t.k);
     const Slot* base = region_of(t, h);
-    uint32_t off = hash_offset(h);
+    uint32_t off = hash_offset(h, t.k);
     for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
         const Slot* s = base + ((off + probe) & (REGION_SLOTS - 1));
         uint64_t cur = s->key;

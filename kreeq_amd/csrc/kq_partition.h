@@ -47,7 +47,7 @@ struct LevelCfg {
     uint64_t n_regions;
     uint32_t n_seg, nb, seg_shift, out_shift;
     uint32_t in_raw;        // 1: the input records hold raw keys (kq_insert_records): this level mixes them
-    uint32_t mix_wide;      // the table's mix width (k > 28), needed when in_raw
+    uint32_t k;             // k-mer length (width of the table's mix), needed when in_raw
 };
 __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, uint64_t region) {
     return (uint32_t)(region >> lv.out_shift) - (lv.seg_shift >= 32 ? 0u : (b << (lv.seg_shift - lv.out_shift)));

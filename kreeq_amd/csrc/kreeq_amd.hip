@@ -143,7 +143,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
         tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
             if (valid) {
                 const uint64_t key = fw < rv ? fw : rv;
-                const uint32_t b = p1_bin(cfg, key, table_hash(key, k > PART_MAX_K));
+                const uint32_t b = p1_bin(cfg, key, table_hash(key, (uint32_t)k));
                 if (b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
             }
         });
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && !WIDE) ? 3 : 2) void k
         tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int i, bool valid, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
             const bool is_fw = fw < rv;
             const uint64_t key = is_fw ? fw : rv;
-            const uint64_t h = table_hash(key, k > PART_MAX_K);             // the only hash of this k-mer on the whole path
+            const uint64_t h = table_hash(key, (uint32_t)k);             // the only hash of this k-mer on the whole path
             if (WIDE) {
                 rec[i] = cfg.raw_out ? key : h;                             // raw keys only for kq_emit_partitioned_dev's caller
                 const uint32_t e = edge_idx6(is_fw, prev, next);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi)
-                    atomicAdd(&s_hist[level_bin(lv, b, hash_region(lv.in_raw ? table_hash(r[j], lv.mix_wide) : rec_hash<WIDE>(r[j]), lv.n_regions))], 1u);
+                    atomicAdd(&s_hist[level_bin(lv, b, hash_region(lv.in_raw ? table_hash(r[j], lv.k) : rec_hash<WIDE>(r[j]), lv.n_regions))], 1u);
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) m2[u * lv.nb + i] = s_hist[i];
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
 #pragma unroll
             for (int j = 0; j < LV_ITEMS; ++j) {
                 const uint64_t i = pos + (uint64_t)j * LV_THREADS + threadIdx.x;
-                rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.mix_wide) : nxt[j];      // raw keys become hashes at the first level
+                rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.k) : nxt[j];      // raw keys become hashes at the first level
                 aux[j] = nxt_aux[j];
                 bin[j] = i < hi ? level_bin(lv, b, hash_region(rec_hash<WIDE>(rec[j]), lv.n_regions)) : nb;
             }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
         // volatile access through a generic pointer compiles to flat_load + s_waitcnt vmcnt(0), which also
         // drains the record prefetches on every probe.
         auto find_slot = [&](uint64_t key, uint64_t h) -> uint32_t {
-            const uint32_t off = hash_offset(h);
+            const uint32_t off = hash_offset(h, t.k);
             for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
                 const uint32_t w = 3u * ((off + probe) & (REGION_SLOTS - 1));
                 uint64_t cur = __hip_atomic_load(&s_img[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
         };
         // `cnt` folded instances of `key` with edge counts e[0..7] (each <= cnt)
         auto apply = [&](uint64_t key, const uint32_t (&e)[8], uint32_t cnt) {
-            const uint64_t h = table_hash(key, t.wide);
+            const uint64_t h = table_hash(key, t.k);
             const uint32_t w = find_slot(key, h);
             if (w == REGION_SLOTS * 3) return;
             n_ok += cnt;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
             uint64_t key = 0, pack = 0;
             const uint64_t h = rec_hash<WIDE>(rec);
             if (active) {
-                key = key_of_hash(h, t.wide);                                   // the mix is a bijection: no key in the record
+                key = key_of_hash(h, t.k);                                   // the mix is a bijection: no key in the record
                 pack = WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
             }
             const uint64_t act = FOLD ? __ballot(active) : 0ull;
@@ -912,7 +912,7 @@ struct kq_handle {
     std::vector<std::pair<const char*, hipEvent_t>> marks;
     void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
 
-    TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; v.wide = k > 28 ? 1u : 0u; return v; }
+    TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; v.k = (uint32_t)k; return v; }
     uint64_t n_slots() const { return n_regions << REGION_SHIFT; }
 };
 
@@ -1345,11 +1345,11 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     mark(h, "k_lv_scatter");
 }
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
-    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.mix_wide = 0;
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0;
     return lv;
 }
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
-    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.mix_wide = 0;
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0;
     return lv;
 }
 static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint8_t* sorted_aux, int aux_fmt, const unsigned long long* base) {
@@ -1402,7 +1402,7 @@ static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const
     uint8_t* a2 = d_aux ? p.aux2 : nullptr;
     hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, h->stream, p.seg_off, 0ull, (unsigned long long)n);
     LevelCfg first = level_flat_to_coarse(p.cfg);
-    first.in_raw = raw ? 1 : 0; first.mix_wide = h->k > 28 ? 1 : 0;
+    first.in_raw = raw ? 1 : 0; first.k = (uint32_t)h->k;
     run_level(h, &p, first, d_recs, d_aux, p.recs1, a1);        // group_base = coarse offsets
     if (p.two_level) {
         // the coarse offsets become the segment table of the next level

@@ -356,18 +356,18 @@ def test_partitioned_wide_records(kq, O, k, hint):
     assert np.array_equal(cg, cc)
 
 
-def _unpack_records(recs):
+def _unpack_records(recs, k):
     """packed 8-byte records (include/kreeq_amd.h: kq_emit_packed_dev) -> (key, reference edge byte)"""
     recs = recs.astype(np.uint64)
-    # bits 0..55 = the invertible 56-bit mix of the key (kq_device.h table_hash): undo it
-    M56, MUL = (1 << 56) - 1, 0x9E3779B97F4A7C15
-    inv = pow(MUL, -1, 1 << 64) & M56
-    x = recs & np.uint64(M56)
-    x = x ^ (x >> np.uint64(28))
-    lo, hi = x & np.uint64(0xFFFFFFF), x >> np.uint64(28)                   # 56-bit modular product from 28-bit limbs
-    il, ih = np.uint64(inv & 0xFFFFFFF), np.uint64(inv >> 28)
-    x = (lo * il + (((lo * ih + hi * il) & np.uint64(0xFFFFFFF)) << np.uint64(28))) & np.uint64(M56)
-    key = x ^ (x >> np.uint64(28))
+    # bits 0..55 = top 56 bits of the left-aligned invertible mix of the key (kq_device.h table_hash): undo it
+    u = np.uint64
+    inv = u(pow(0x9E3779B97F4A7C15, -1, 1 << 64))
+    pad, kk = u(64 - 2 * k), u(k)
+    h = recs << u(8)
+    with np.errstate(over="ignore"):
+        x = (h ^ ((h >> kk) & (~u(0) << pad))) >> pad
+        x = ((x * inv) << pad) >> pad
+    key = x ^ (x >> kk)
     f = ((recs >> np.uint64(56)) & np.uint64(7)).astype(np.int64)
     b = ((recs >> np.uint64(59)) & np.uint64(7)).astype(np.int64)
     edge = np.where(f < 4, 1 << (7 - np.minimum(f, 3)), 0) | np.where(b < 4, 1 << (7 - (4 + np.minimum(b, 3))), 0)
@@ -390,7 +390,7 @@ def test_packed_emit_exchange_insert(kq, O, k, hint):
         counts = src.emit_packed_dev(t.data_ptr(), len(batch), n_parts, recs.data_ptr(), len(batch))
         assert int(counts.sum()) == len(ok)
         host = recs[:len(ok)].cpu().numpy().astype(np.uint64)
-        key, edge = _unpack_records(host)
+        key, edge = _unpack_records(host, k)
         # same multiset of (key, edge) records as the reference loop 1
         a = np.sort(key.astype(np.uint64) * np.uint64(256) + edge)[:0]  # (overflow-safe compare below)
         got = np.stack([key, edge.astype(np.uint64)], axis=1)
