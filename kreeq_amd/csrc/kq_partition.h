@@ -36,6 +36,7 @@ struct PartCfg {
     uint32_t map_mask;    // map_count - 1 when it is a power of two, else 0
     uint32_t filt_lo, filt_hi;   // count only k-mers whose map index key % map_count lies in [filt_lo, filt_hi)
     uint32_t raw_out;     // 1: WIDE records carry the raw key (kq_emit_partitioned_dev), else its table hash
+    uint32_t narrow;      // 1: bin = top NARROW_CBITS hash bits (n_regions is a multiple of 2^NARROW_CBITS), FMT_NARROW records
 };
 
 // One level of the record split.  Input records are grouped in n_seg segments (seg_off[0..n_seg]);
@@ -48,6 +49,7 @@ struct LevelCfg {
     uint32_t n_seg, nb, seg_shift, out_shift;
     uint32_t in_raw;        // 1: the input records hold raw keys (kq_insert_records): this level mixes them
     uint32_t k;             // k-mer length (width of the table's mix), needed when in_raw
+    uint32_t narrow;        // 1: FMT_NARROW records, segment b = hash-prefix bucket b owning regions [b * nb, (b + 1) * nb)
 };
 __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, uint64_t region) {
     return (uint32_t)(region >> lv.out_shift) - (lv.seg_shift >= 32 ? 0u : (b << (lv.seg_shift - lv.out_shift)));
@@ -85,14 +87,35 @@ __device__ __forceinline__ uint64_t rec_pack_hash(uint64_t h, bool is_fw, uint32
     return (h >> 8) | ((uint64_t)edge_idx6(is_fw, prev, next) << REC_EDGE_SHIFT);
 }
 
+// Record formats of the partitioned path:
+//   FMT_PACK8  (k <= 28)  one u64: top 56 bits of the table hash | two 3-bit edge indices at bits 56..61
+//   FMT_WIDE   (any k)    u64 table hash (or raw key, see LevelCfg::in_raw) + lockstep u8 (AUX_IDX6 / AUX_EDGE_BYTE)
+//   FMT_NARROW (k <= 21, two-level split with 256 top-bit buckets) u32 + lockstep u8: after P1 the top 8
+//              hash bits are the bucket a record lies in, the remaining <= 34 bits are the u32 (upper 32) and the
+//              low 2 bits of the u8, whose upper 6 bits are the edge indices.  5 bytes instead of 8 through
+//              three of the four record passes, and the level histogram reads only the u32 array.
+constexpr int FMT_PACK8 = 0, FMT_WIDE = 1, FMT_NARROW = 2;
+constexpr uint32_t NARROW_CBITS = 8, NARROW_MAX_K = 21;
+__device__ __forceinline__ uint32_t narrow_main(uint64_t h) { return (uint32_t)(h >> (32 - NARROW_CBITS)); }
+__device__ __forceinline__ uint32_t narrow_aux(uint64_t h, uint32_t idx6) { return ((uint32_t)(h >> (30 - NARROW_CBITS)) & 3u) | (idx6 << 2); }
+__device__ __forceinline__ uint64_t narrow_hash(uint32_t bucket, uint32_t main32, uint32_t aux) {
+    return ((uint64_t)bucket << (64 - NARROW_CBITS)) | ((uint64_t)main32 << (32 - NARROW_CBITS)) | ((uint64_t)(aux & 3u) << (30 - NARROW_CBITS));
+}
+// region of a narrow record of bucket b: the top 32 hash bits are b's 8 bits over the top 24 of the u32
+__device__ __forceinline__ uint32_t narrow_region(uint32_t bucket, uint32_t main32, uint64_t n_regions) {
+    return __umulhi((bucket << (32 - NARROW_CBITS)) | (main32 >> NARROW_CBITS), (uint32_t)n_regions);
+}
+
 // LDS of one multisplit workgroup.  NBC = bin capacity (incl. the discard bin): 512 keeps the whole
 // struct at 48 KiB (three workgroups per CU) and covers the usual fan-outs; 2048 (72-76 KiB, two per
 // CU) is the general case.
-template <int NBC, bool WIDE>
+template <int FMT> struct rec_word { using type = uint64_t; };
+template <> struct rec_word<FMT_NARROW> { using type = uint32_t; };
+template <int NBC, int FMT>
 struct MsShared {
-    uint64_t stage[MS_TILE];                 // 32 KiB
+    typename rec_word<FMT>::type stage[MS_TILE];   // 32 KiB (16 KiB for narrow records)
     uint16_t sbin[MS_TILE];                  //  8 KiB
-    uint8_t  saux[WIDE ? MS_TILE : 8];       //  4 KiB   (WIDE records only)
+    uint8_t  saux[FMT != FMT_PACK8 ? MS_TILE : 8];   //  4 KiB   (records with a lockstep byte)
     uint32_t hist[NBC];
     uint32_t loff[NBC];
     unsigned long long gbase[NBC];
@@ -147,7 +170,7 @@ __device__ __forceinline__ void ms_scan(S& s, uint32_t nb) {
 __device__ __forceinline__ void landed(uint32_t& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void landed(uint64_t& v) { asm volatile("" : "+v"(v)); }
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <bool WIDE, int THREADS = MS_THREADS, int ITEMS = MS_ITEMS, class S, class F = NoHook>
+template <int FMT, int THREADS = MS_THREADS, int ITEMS = MS_ITEMS, class S, class F = NoHook>
 __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITEMS], const uint32_t (&aux)[ITEMS],
                                                  const uint32_t (&bin)[ITEMS], uint32_t nb,
                                                  uint64_t* __restrict__ out, uint8_t* __restrict__ out_aux, F pre_store = F()) {
@@ -167,9 +190,9 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t p = s.loff[bin[i]] + rank[i];
-        s.stage[p] = rec[i];
+        s.stage[p] = (typename rec_word<FMT>::type)rec[i];
         s.sbin[p] = (uint16_t)bin[i];
-        if (WIDE) s.saux[p] = (uint8_t)aux[i];
+        if (FMT != FMT_PACK8) s.saux[p] = (uint8_t)aux[i];
     }
     __syncthreads();
     KQ_MS_STAMP(s, 4);                            // stage writes + barrier
@@ -193,8 +216,9 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t j = tid + it * THREADS;
         if (j < total) {
-            out[cg[it]] = cv[it];
-            if (WIDE) out_aux[cg[it]] = s.saux[j];
+            if (FMT == FMT_NARROW) reinterpret_cast<uint32_t*>(out)[cg[it]] = (uint32_t)cv[it];
+            else out[cg[it]] = cv[it];
+            if (FMT != FMT_PACK8) out_aux[cg[it]] = s.saux[j];
         }
     }
     __syncthreads();
@@ -217,7 +241,7 @@ __device__ __forceinline__ uint32_t p1_bin(const PartCfg& cfg, uint64_t key, uin
         const uint32_t m = map_index(key, cfg.map_count, cfg.map_mask);
         if (m < cfg.filt_lo || m >= cfg.filt_hi) return cfg.n_coarse;
     }
-    return cfg.mode == 0 ? (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift)
+    return cfg.mode == 0 ? (cfg.narrow ? (uint32_t)(h >> (64 - NARROW_CBITS)) : (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift))
                          : owner_part_of(key, cfg.map_count, cfg.map_mask, cfg.n_coarse);
 }
 

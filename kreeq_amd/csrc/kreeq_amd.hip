@@ -162,13 +162,14 @@ __global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const un
     if (b == cfg.n_coarse) coarse_off[b] = *total;
 }
 // P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
-template <bool WIDE, int NBC>
-__global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && !WIDE) ? 3 : 2) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+template <int FMT, int NBC>
+__global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 : 2) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
                                                              PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
                                                              uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
-    __shared__ MsShared<NBC, WIDE> s;
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW;
+    __shared__ MsShared<NBC, FMT> s;
     const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
     const uint64_t n_tiles = n_tiles_of(lead, len);
     const uint64_t cols = (uint64_t)gridDim.x * P1_F;
@@ -191,13 +192,16 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && !WIDE) ? 3 : 2) void k
                 rec[i] = cfg.raw_out ? key : h;                             // raw keys only for kq_emit_partitioned_dev's caller
                 const uint32_t e = edge_idx6(is_fw, prev, next);
                 aux[i] = aux_fmt == AUX_IDX6 ? e : idx6_to_edge_byte(e);
+            } else if (NARROW) {
+                rec[i] = narrow_main(h);
+                aux[i] = narrow_aux(h, edge_idx6(is_fw, prev, next));
             } else {
                 rec[i] = rec_pack_hash(h, is_fw, prev, next);
                 aux[i] = 0;
             }
             bin[i] = valid ? p1_bin(cfg, key, h) : cfg.n_coarse;
         });
-        block_multisplit<WIDE>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux,
+        block_multisplit<FMT>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux,
                                [&] { landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w); });   // ends with a barrier
     }
 }
@@ -222,7 +226,7 @@ __device__ __forceinline__ uint32_t seg_of_unit(const unsigned long long* unit_b
     return lo;
 }
 // pass A: per-unit bin counts -> M2[unit][bin] (u32)
-template <bool WIDE>
+template <int FMT>
 __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restrict__ recs, LevelCfg lv,
                                                         const unsigned long long* __restrict__ seg_off,
                                                         const unsigned long long* __restrict__ unit_base, uint32_t* __restrict__ m2) {
@@ -240,11 +244,17 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
         for (uint64_t base = lo; base < hi; base += 8ull * MS_THREADS) {
             uint64_t r[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = recs[min(base + (uint64_t)j * MS_THREADS + threadIdx.x, last)];
+            for (int j = 0; j < 8; ++j) {
+                const uint64_t i = min(base + (uint64_t)j * MS_THREADS + threadIdx.x, last);
+                r[j] = FMT == FMT_NARROW ? (uint64_t)reinterpret_cast<const uint32_t*>(recs)[i] : recs[i];      // narrow: the u32 array alone decides the bin
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi)
-                    atomicAdd(&s_hist[level_bin(lv, b, hash_region(lv.in_raw ? table_hash(r[j], lv.k) : rec_hash<WIDE>(r[j]), lv.n_regions))], 1u);
+                if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi) {
+                    const uint32_t bin = FMT == FMT_NARROW ? narrow_region(b, (uint32_t)r[j], lv.n_regions) - b * lv.nb
+                        : level_bin(lv, b, hash_region(lv.in_raw ? table_hash(r[j], lv.k) : rec_hash<FMT == FMT_WIDE>(r[j]), lv.n_regions));
+                    atomicAdd(&s_hist[bin], 1u);
+                }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) m2[u * lv.nb + i] = s_hist[i];
@@ -280,13 +290,15 @@ __global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, L
 #define KQ_LV_OCC 4
 #endif
 constexpr int LV_THREADS = KQ_LV_THREADS, LV_ITEMS = KQ_LV_ITEMS, LV_TILE = LV_THREADS * LV_ITEMS;       // records come from memory: more waves per LDS footprint
-template <bool WIDE, int NBC>
+template <int FMT, int NBC>
 __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
                                                            const unsigned long long* __restrict__ seg_off,
                                                            const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
                                                            const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out,
                                                            uint8_t* __restrict__ out_aux) {
-    __shared__ MsShared<NBC, WIDE> s;
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, HAS_AUX = FMT != FMT_PACK8;
+    const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
+    __shared__ MsShared<NBC, FMT> s;
     const uint32_t nb = lv.nb;
     const uint64_t n_units = unit_base[lv.n_seg];
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
@@ -307,13 +319,13 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
 #pragma unroll
         for (int j = 0; j < LV_ITEMS; ++j) {
             const uint64_t i = min(lo + (uint64_t)j * LV_THREADS + threadIdx.x, last);
-            nxt[j] = recs[i];
-            nxt_aux[j] = WIDE ? recs_aux[i] : 0;
+            nxt[j] = NARROW ? (uint64_t)recs32[i] : recs[i];
+            nxt_aux[j] = HAS_AUX ? recs_aux[i] : 0;
         }
         // wait for the first round's records HERE: otherwise the loop header inherits "loads pending" from
         // this path and its s_waitcnt vmcnt(0) also drains the previous round's stores on the back edge
 #pragma unroll
-        for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (WIDE) landed(nxt_aux[j]); }
+        for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (HAS_AUX) landed(nxt_aux[j]); }
         for (uint64_t pos = lo; pos < hi; pos += LV_TILE) {
             uint64_t rec[LV_ITEMS];
             uint32_t aux[LV_ITEMS], bin[LV_ITEMS];
@@ -322,17 +334,18 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                 const uint64_t i = pos + (uint64_t)j * LV_THREADS + threadIdx.x;
                 rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.k) : nxt[j];      // raw keys become hashes at the first level
                 aux[j] = nxt_aux[j];
-                bin[j] = i < hi ? level_bin(lv, b, hash_region(rec_hash<WIDE>(rec[j]), lv.n_regions)) : nb;
+                bin[j] = i >= hi ? nb : NARROW ? narrow_region(b, (uint32_t)rec[j], lv.n_regions) - b * nb
+                                               : level_bin(lv, b, hash_region(rec_hash<WIDE>(rec[j]), lv.n_regions));
             }
 #pragma unroll
             for (int j = 0; j < LV_ITEMS; ++j) {
                 const uint64_t i = min(pos + LV_TILE + (uint64_t)j * LV_THREADS + threadIdx.x, last);
-                nxt[j] = recs[i];
-                nxt_aux[j] = WIDE ? recs_aux[i] : 0;
+                nxt[j] = NARROW ? (uint64_t)recs32[i] : recs[i];
+                nxt_aux[j] = HAS_AUX ? recs_aux[i] : 0;
             }
-            block_multisplit<WIDE, LV_THREADS, LV_ITEMS>(s, rec, aux, bin, nb, out, out_aux, [&] {
+            block_multisplit<FMT, LV_THREADS, LV_ITEMS>(s, rec, aux, bin, nb, out, out_aux, [&] {
 #pragma unroll
-                for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (WIDE) landed(nxt_aux[j]); }
+                for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (HAS_AUX) landed(nxt_aux[j]); }
             });
         }
     }
@@ -400,10 +413,13 @@ constexpr int P3_THREADS = 512;        // three 48 KiB images per CU (24 waves):
 // Two instantiations share the regions: HOT = false takes the ordinary ones (deep record prefetch, no
 // folding state: fits the 80 VGPRs that let three workgroups share a CU) and appends the skewed ones
 // to hot_list; HOT = true then walks that list with the folding loop.
-template <bool WIDE, bool HOT>
+template <int FMT, bool HOT>
 __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
                                                               int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty,
-                                                              unsigned long long* __restrict__ hot_list /*[0] = count, then region ids*/) {
+                                                              unsigned long long* __restrict__ hot_list /*[0] = count, then region ids*/,
+                                                              uint32_t narrow_rps /*FMT_NARROW: regions per top-bit bucket*/) {
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, HAS_AUX = FMT != FMT_PACK8;
+    const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
     __shared__ unsigned long long s_new, s_kmers;
     __shared__ unsigned int s_grp;
@@ -420,6 +436,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
     for (uint64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
         const uint64_t r = HOT ? hot_list[1 + w] : w;
         const uint64_t lo = region_base[r], hi = region_base[r + 1];
+        const uint32_t narrow_bucket = NARROW ? (uint32_t)r / narrow_rps : 0u;
         if (lo == hi) {                                                 // block-uniform
             if (!HOT && table_is_empty == 2) {    // lazy kq_clear: this launch initialises every region, also the ones without records
                 ulonglong2* g2 = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
@@ -547,8 +564,8 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             const uint64_t j = min(lo + g_cur * GRP + (uint64_t)q * 64 + lane, last);
-            nxt_rec[q] = recs[j];
-            nxt_aux[q] = WIDE ? recs_aux[j] : 0u;
+            nxt_rec[q] = NARROW ? (uint64_t)recs32[j] : recs[j];
+            nxt_aux[q] = HAS_AUX ? recs_aux[j] : 0u;
         }
         while (lo + g_cur * GRP < hi) {                                 // wave-uniform
           uint64_t cur_rec[PF];
@@ -561,8 +578,8 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
 #pragma unroll
           for (int q = 0; q < PF; ++q) {
             const uint64_t j = min(lo + g_nxt * GRP + (uint64_t)q * 64 + lane, last);
-            nxt_rec[q] = recs[j];
-            nxt_aux[q] = WIDE ? recs_aux[j] : 0u;
+            nxt_rec[q] = NARROW ? (uint64_t)recs32[j] : recs[j];
+            nxt_aux[q] = HAS_AUX ? recs_aux[j] : 0u;
           }
           const uint64_t base = lo + g_cur * GRP;
           g_cur = g_nxt;
@@ -573,10 +590,11 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
             const uint64_t rec = cur_rec[q];
             const uint32_t aux = cur_aux[q];
             uint64_t key = 0, pack = 0;
-            const uint64_t h = rec_hash<WIDE>(rec);
+            const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec, aux) : rec_hash<WIDE>(rec);
             if (active) {
                 key = key_of_hash(h, t.k);                                   // the mix is a bijection: no key in the record
-                pack = WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
+                pack = NARROW ? idx6_to_pack(aux >> 2)
+                     : WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
             }
             const uint64_t act = FOLD ? __ballot(active) : 0ull;
             if (FOLD && act) {
@@ -1121,6 +1139,7 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
         uint64_t slots = (uint64_t)((double)(capacity_hint ? capacity_hint : (1u << 20)) / 0.7);   // load <= 0.7 at the hinted size
         uint64_t regions = (slots + REGION_SLOTS - 1) >> REGION_SHIFT;
         if (regions < 16) regions = 16;
+        if (regions >= (uint64_t)NB_MAX) regions = (regions + 255) / 256 * 256;      // FMT_NARROW: 256 hash-prefix buckets of whole regions
         rc = alloc_main(h, regions, &h->slots); if (rc) break;
         h->n_regions = regions;
         uint64_t hc = 1u << 16;
@@ -1228,6 +1247,7 @@ int kq_get_info(kq_handle* h, kq_info* out) {
 struct PartPlan {
     PartCfg cfg;              // P1 (bases -> coarse buckets)
     bool two_level;
+    int fmt;                  // record format between the stages (FMT_*)
     uint64_t n_max, R;
     uint32_t g1;              // P1 scatter workgroups
     uint64_t m1_n, m2_n, sums_n, groups_n;
@@ -1237,7 +1257,7 @@ struct PartPlan {
     unsigned long long *m1, *seg_off, *unit_base, *group_base, *sums, *total, *hot;
     uint32_t* m2;
 };
-static void plan_cfg(const kq_handle* h, PartCfg* cfg) {
+static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false) {
     cfg->n_regions = h->n_regions;
     // fan-outs: the first split (fused with the sequence scan) is insensitive to its fan-out up to
     // ~512 bins, the second is bound by the length of the runs it writes (4096 / fan-out records), so
@@ -1252,15 +1272,21 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg) {
     cfg->map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
     cfg->filt_lo = 0; cfg->filt_hi = (uint32_t)h->map_count;
     cfg->raw_out = 0;
+    // 5-byte records (FMT_NARROW): first split on the top 8 hash bits, which needs every bucket to own a
+    // whole number of regions (kq_create rounds large tables to a multiple of 256 regions; doubling keeps it)
+    cfg->narrow = allow_narrow && h->k <= (int)NARROW_MAX_K && cfg->g_shift != 0 && cfg->n_regions % (1u << NARROW_CBITS) == 0 &&
+                  (cfg->n_regions >> NARROW_CBITS) < (uint64_t)NB_MAX ? 1u : 0u;
+    if (cfg->narrow) cfg->n_coarse = 1u << NARROW_CBITS;
 }
 // carve the scratch buffer for a batch of at most n_max records; n_tiles = 0 when the input is records
-static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins) {
-    plan_cfg(h, &p->cfg);
+static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins, bool allow_narrow = false) {
+    plan_cfg(h, &p->cfg, allow_narrow);
     p->two_level = p->cfg.g_shift != 0;
+    p->fmt = p->cfg.narrow ? FMT_NARROW : FMT_PACK8;          // the caller switches to FMT_WIDE where it applies
     p->n_max = n_max; p->R = p->cfg.n_regions;
     p->g1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (p1_bins < 512 ? 3 : 2)));
     p->m1_n = (uint64_t)p1_bins * p->g1 * P1_F;
-    const uint64_t nb_max = std::max<uint64_t>(1ull << p->cfg.g_shift, p->cfg.n_coarse);
+    const uint64_t nb_max = std::max<uint64_t>(std::max<uint64_t>(1ull << p->cfg.g_shift, p->cfg.n_coarse), p->cfg.narrow ? p->cfg.n_regions >> NARROW_CBITS : 0);
     p->m2_n = (n_max / P2_UNIT + NB_MAX + 2) * nb_max;         // u32 entries, enough for either level
     p->groups_n = std::max<uint64_t>(p->R, (uint64_t)p->cfg.n_coarse << p->cfg.g_shift) + 2;
     p->sums_n = std::max(p->m1_n, p->groups_n) / SCAN_CHUNK + 2;
@@ -1316,22 +1342,24 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     mark(h, "k_p1_hist+scan");
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
 #define KQ_P1S(W, N) hipLaunchKernelGGL((k_p1_scatter<W, N>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt)
-    if (out_aux) { if (small) KQ_P1S(true, 512); else KQ_P1S(true, NB_MAX); }
-    else         { if (small) KQ_P1S(false, 512); else KQ_P1S(false, NB_MAX); }
+    if (cfg.narrow)   { KQ_P1S(FMT_NARROW, 512); }                                                    // 256 buckets
+    else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512); else KQ_P1S(FMT_WIDE, NB_MAX); }
+    else              { if (small) KQ_P1S(FMT_PACK8, 512); else KQ_P1S(FMT_PACK8, NB_MAX); }
 #undef KQ_P1S
     mark(h, "k_p1_scatter");
 }
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
 // afterwards p->group_base[0..n_seg*nb] are the output offsets
 static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint64_t* in, const uint8_t* in_aux, uint64_t* out, uint8_t* out_aux) {
-    const bool wide = in_aux != nullptr;
+    const int fmt = lv.narrow ? FMT_NARROW : in_aux != nullptr ? FMT_WIDE : FMT_PACK8;
     const uint64_t groups = (uint64_t)lv.n_seg * lv.nb;
     hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, lv, p->unit_base);
     // one workgroup per work unit (upper bound of the unit count; surplus workgroups exit at once):
     // the hardware dispatcher balances them, a fixed grid looping over units left a 30 % tail
     const unsigned unit_grid = (unsigned)std::min<uint64_t>(p->n_max / P2_UNIT + lv.n_seg + 1, 1u << 30);
-    if (wide) hipLaunchKernelGGL(k_lv_hist<true>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
-    else hipLaunchKernelGGL(k_lv_hist<false>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    if (fmt == FMT_NARROW) hipLaunchKernelGGL(k_lv_hist<FMT_NARROW>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    else if (fmt == FMT_WIDE) hipLaunchKernelGGL(k_lv_hist<FMT_WIDE>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    else hipLaunchKernelGGL(k_lv_hist<FMT_PACK8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
     (void)hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
     scan_u64(h, p->group_base, groups + 1, p->sums, p->total + 1);
@@ -1339,17 +1367,24 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     const bool small = lv.nb < 512;
 #define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
                                         p->seg_off, p->unit_base, p->m2, p->group_base, out, out_aux)
-    if (wide) { if (small) KQ_LVS(true, 512); else KQ_LVS(true, NB_MAX); }
-    else      { if (small) KQ_LVS(false, 512); else KQ_LVS(false, NB_MAX); }
+    if (fmt == FMT_NARROW)    { if (small) KQ_LVS(FMT_NARROW, 512); else KQ_LVS(FMT_NARROW, NB_MAX); }
+    else if (fmt == FMT_WIDE) { if (small) KQ_LVS(FMT_WIDE, 512); else KQ_LVS(FMT_WIDE, NB_MAX); }
+    else                      { if (small) KQ_LVS(FMT_PACK8, 512); else KQ_LVS(FMT_PACK8, NB_MAX); }
 #undef KQ_LVS
     mark(h, "k_lv_scatter");
 }
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
-    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0;
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 0;
+    return lv;
+}
+// FMT_NARROW: 256 top-bit buckets -> their regions (bucket b owns regions [b * nb, (b + 1) * nb))
+static LevelCfg level_narrow(const PartCfg& cfg) {
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1u << NARROW_CBITS; lv.nb = (uint32_t)(cfg.n_regions >> NARROW_CBITS);
+    lv.seg_shift = 0; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 1;
     return lv;
 }
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
-    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0;
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0; lv.narrow = 0;
     return lv;
 }
 static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint8_t* sorted_aux, int aux_fmt, const unsigned long long* base) {
@@ -1358,31 +1393,33 @@ static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint
     (void)hipMemsetAsync(hot, 0, 8, h->stream);
     const dim3 grid((unsigned)std::min<uint64_t>(p->R, 1u << 30)), grid_hot(h->n_cu), block(P3_THREADS);   // one workgroup per region: dispatcher-balanced
     const int empty = h->table_empty ? (h->slots_dirty ? 2 : 1) : 0;       // 2: also write the image of regions without records
-    if (sorted_aux) {
-        hipLaunchKernelGGL((k_count_regions<true, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
-        hipLaunchKernelGGL((k_count_regions<true, true>), grid_hot, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
-    } else {
-        hipLaunchKernelGGL((k_count_regions<false, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
-        hipLaunchKernelGGL((k_count_regions<false, true>), grid_hot, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot);
-    }
+    const uint32_t rps = p->fmt == FMT_NARROW ? (uint32_t)(p->R >> NARROW_CBITS) : 1u;
+#define KQ_P3(F) do { \
+        hipLaunchKernelGGL((k_count_regions<F, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot, rps); \
+        hipLaunchKernelGGL((k_count_regions<F, true>), grid_hot, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot, rps); } while (0)
+    if (p->fmt == FMT_NARROW) KQ_P3(FMT_NARROW);
+    else if (sorted_aux) KQ_P3(FMT_WIDE);
+    else KQ_P3(FMT_PACK8);
+#undef KQ_P3
     h->slots_dirty = false;          // every region has been written
 }
 
 // partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
 static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er) {
     PartPlan p;
-    PartCfg c0; plan_cfg(h, &c0);
-    int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), c0.n_coarse);
+    PartCfg c0; plan_cfg(h, &c0, true);
+    int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), c0.n_coarse, true);
     if (rc) return rc;
-    const bool wide = h->k > PART_MAX_K;                       // 8-byte packed records up to k = 28, key + edge byte above
-    uint8_t* a1 = wide ? p.aux1 : nullptr;
-    uint8_t* a2 = wide ? p.aux2 : nullptr;
+    const bool wide = h->k > PART_MAX_K;                       // 5-byte records up to k = 21 (large tables), 8-byte packed up to k = 28, hash + edge byte above
+    if (wide) p.fmt = FMT_WIDE;
+    uint8_t* a1 = p.fmt != FMT_PACK8 ? p.aux1 : nullptr;
+    uint8_t* a2 = p.fmt != FMT_PACK8 ? p.aux2 : nullptr;
     p.cfg.filt_lo = h->filt_lo; p.cfg.filt_hi = h->filt_hi;      // KQ_OPT_COUNT_MAP_RANGE
     marks_reset(h);
     mark(h, "start");
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
     if (p.two_level) {
-        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
+        run_level(h, &p, p.fmt == FMT_NARROW ? level_narrow(p.cfg) : level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
         run_p3(h, &p, p.recs2, a2, AUX_IDX6, p.group_base);
     } else {
         run_p3(h, &p, p.recs1, a1, AUX_IDX6, p.seg_off);       // bins were the regions themselves
@@ -1398,6 +1435,7 @@ static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const
     PartPlan p;
     int rc = plan_alloc(h, &p, n, 0, 1);
     if (rc) return rc;
+    if (d_aux) p.fmt = FMT_WIDE;
     uint8_t* a1 = d_aux ? p.aux1 : nullptr;
     uint8_t* a2 = d_aux ? p.aux2 : nullptr;
     hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, h->stream, p.seg_off, 0ull, (unsigned long long)n);

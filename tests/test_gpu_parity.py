@@ -579,3 +579,51 @@ def test_count_map_range_filter(kq, O, path):
     assert np.array_equal(ctr, cc)
     with pytest.raises(kq.KqError):
         whole.set_option("count_map_range", (5, 5))
+
+
+# ---------------------------------------------------------------------------------- 5-byte (narrow) records
+@pytest.mark.parametrize("k,hint", [(21, 5_000_000), (20, 3_100_000), (13, 3_000_000), (21, 40_000_000), (22, 5_000_000)])
+def test_narrow_record_path_vs_oracle(kq, O, k, hint):
+    """tables of >= 2048 regions are rounded to a multiple of 256 regions, and k <= 21 then splits on the top
+    8 hash bits with 5-byte records (k = 22 is the first k on the 8-byte path with the same geometry).
+    Two batches (k_count_regions merges into existing regions), N runs, a map-range filtered handle."""
+    batch, genome = H.synth_reads(40000, 150, 200000, seed=300 + k, err=0.01, n_rate=0.003)
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=hint), O.OracleDB(k, 128)
+    gpu.set_option("count_path", "partitioned")
+    info = gpu.info()
+    assert info["slots_total"] % (256 * 2048) == 0                  # the geometry the narrow path needs
+    cut = batch.rfind(b"\n", 0, len(batch) // 2)
+    for part in (batch[:cut], batch[cut + 1:]):
+        gpu.count_batch(part)
+        cpu.count_batch(part, threads=8)
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    full = cpu.export()
+    assert H.entries_equal(gpu.export(), full)
+    cg, _ = gpu.lookup_sequence(genome)
+    cc, _ = cpu.validate_sequence(genome, threads=8)
+    assert np.array_equal(cg, cc)
+    piece = kq.KreeqDB(k, 128, capacity_hint=hint)
+    piece.set_option("count_path", "partitioned")
+    piece.set_option("count_map_range", (17, 90))
+    piece.count_batch(batch)
+    m = full["key"] % 128
+    assert H.entries_equal(piece.export(), full[(m >= 17) & (m < 90)])
+
+
+def test_narrow_records_hot_kmers_and_growth(kq, O):
+    """skewed input (homopolymers: one region takes most records -> hot-region launch) on the narrow path,
+    then a batch that makes the table double (the doubled table keeps the 256-region granularity)"""
+    rng = np.random.default_rng(5)
+    reads = [b"A" * 900, b"T" * 700, b"AC" * 300, b"ACGT" * 200]
+    hot = b"\n".join(reads[i] for i in rng.integers(0, 4, 600))
+    mixed, _ = H.synth_reads(30000, 150, 100000, seed=77, err=0.02, n_rate=0.005)
+    big, _ = H.synth_reads(50000, 150, 5_000_000, seed=78, err=0.0)
+    gpu, cpu = kq.KreeqDB(21, 128, capacity_hint=3_000_000), O.OracleDB(21, 128)
+    gpu.set_option("count_path", "partitioned")
+    before = gpu.info()["slots_total"]
+    for b in (hot, mixed, hot + b"\n" + mixed, big):
+        gpu.count_batch(b)
+        cpu.count_batch(b, threads=8)
+    assert gpu.info()["slots_total"] > before and gpu.info()["slots_total"] % (256 * 2048) == 0
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(gpu.export(), cpu.export())
