@@ -109,13 +109,11 @@ __device__ __forceinline__ uint32_t narrow_region(uint32_t bucket, uint32_t main
 // LDS of one multisplit workgroup.  NBC = bin capacity (incl. the discard bin): 512 keeps the whole
 // struct at 48 KiB (three workgroups per CU) and covers the usual fan-outs; 2048 (72-76 KiB, two per
 // CU) is the general case.
-template <int FMT> struct rec_word { using type = uint64_t; };
-template <> struct rec_word<FMT_NARROW> { using type = uint32_t; };
 template <int NBC, int FMT>
 struct MsShared {
-    typename rec_word<FMT>::type stage[MS_TILE];   // 32 KiB (16 KiB for narrow records)
-    uint16_t sbin[MS_TILE];                  //  8 KiB
-    uint8_t  saux[FMT != FMT_PACK8 ? MS_TILE : 8];   //  4 KiB   (records with a lockstep byte)
+    uint64_t stage[MS_TILE];                 // 32 KiB; narrow records are staged as ONE word: u32 | bin << 32 | byte << 48
+    uint16_t sbin[FMT != FMT_NARROW ? MS_TILE : 4];  //  8 KiB
+    uint8_t  saux[FMT == FMT_WIDE ? MS_TILE : 8];    //  4 KiB   (WIDE records only)
     uint32_t hist[NBC];
     uint32_t loff[NBC];
     unsigned long long gbase[NBC];
@@ -187,12 +185,19 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     KQ_MS_STAMP(s, 2);                            // rank atomics + barrier
     ms_scan<THREADS>(s, nb + 1);
     KQ_MS_STAMP(s, 3);                            // scan (2 barriers)
+    // from here to the end of the round gbase[b] is relative to the staged order: the output index of the
+    // staged record j of bin b is gbase[b] + j (one LDS read per record in the copy-out instead of two)
+    for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] -= s.loff[b];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t p = s.loff[bin[i]] + rank[i];
-        s.stage[p] = (typename rec_word<FMT>::type)rec[i];
-        s.sbin[p] = (uint16_t)bin[i];
-        if (FMT != FMT_PACK8) s.saux[p] = (uint8_t)aux[i];
+        if (FMT == FMT_NARROW) {
+            s.stage[p] = (rec[i] & 0xFFFFFFFFull) | ((uint64_t)bin[i] << 32) | ((uint64_t)aux[i] << 48);    // one 8-byte write, no sub-dword traffic
+        } else {
+            s.stage[p] = rec[i];
+            s.sbin[p] = (uint16_t)bin[i];
+            if (FMT == FMT_WIDE) s.saux[p] = (uint8_t)aux[i];
+        }
     }
     __syncthreads();
     KQ_MS_STAMP(s, 4);                            // stage writes + barrier
@@ -200,15 +205,16 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     // fully unrolled so that the LDS reads of all ITEMS positions are in flight together (a rolled
     // loop is a chain of three dependent LDS round trips per record)
     uint32_t cb[ITEMS];
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) { const uint32_t j = tid + it * THREADS; cb[it] = j < total ? s.sbin[j] : 0u; }
     uint64_t cg[ITEMS], cv[ITEMS];
+    if (FMT == FMT_NARROW) {
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const uint32_t j = tid + it * THREADS;
-        cg[it] = s.gbase[cb[it]] + (j - s.loff[cb[it]]);
-        cv[it] = s.stage[j];
+        for (int it = 0; it < ITEMS; ++it) { cv[it] = s.stage[tid + it * THREADS]; cb[it] = (uint32_t)(cv[it] >> 32) & 0xFFFFu; }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) { const uint32_t j = tid + it * THREADS; cb[it] = j < total ? s.sbin[j] : 0u; cv[it] = s.stage[j]; }
     }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) cg[it] = s.gbase[cb[it]] + (tid + it * THREADS);
     KQ_MS_STAMP(s, 5);                            // copy-out LDS reads
     pre_store();
     KQ_MS_STAMP(s, 6);                            // prefetch landed
@@ -216,15 +222,19 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t j = tid + it * THREADS;
         if (j < total) {
-            if (FMT == FMT_NARROW) reinterpret_cast<uint32_t*>(out)[cg[it]] = (uint32_t)cv[it];
-            else out[cg[it]] = cv[it];
-            if (FMT != FMT_PACK8) out_aux[cg[it]] = s.saux[j];
+            if (FMT == FMT_NARROW) {
+                reinterpret_cast<uint32_t*>(out)[cg[it]] = (uint32_t)cv[it];
+                out_aux[cg[it]] = (uint8_t)(cv[it] >> 48);
+            } else {
+                out[cg[it]] = cv[it];
+                if (FMT == FMT_WIDE) out_aux[cg[it]] = s.saux[j];
+            }
         }
     }
     __syncthreads();
     KQ_MS_STAMP(s, 7);                            // global stores issued + barrier
     // advance the cursors; the same thread zeroes hist[b] at the start of the next round
-    for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] += s.hist[b];
+    for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] += s.loff[b] + s.hist[b];       // back to absolute, advanced
 }
 
 // owner part of a key in the multi-GPU exchange: floor((key % map_count) * n_parts / map_count)

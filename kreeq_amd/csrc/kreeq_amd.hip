@@ -241,6 +241,27 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
         // 8 records per lane in flight, loaded unconditionally (index clamped): a load inside a branch per
         // iteration costs a full memory latency per record (s_waitcnt vmcnt(0) right behind it)
         const uint64_t last = hi - 1;                                   // a unit is never empty
+        if (FMT == FMT_NARROW) {
+            // 16-byte loads of four u32 records at absolute quad indices (the array is 16-byte aligned and has
+            // slack behind its last record); the quads at the unit's ends are masked per element
+            const uint4* v4 = reinterpret_cast<const uint4*>(recs);
+            const uint64_t q0 = lo >> 2, q1 = (hi + 3) >> 2;
+            for (uint64_t qb = q0; qb < q1; qb += 4ull * MS_THREADS) {
+                uint4 q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = v4[min(qb + (uint64_t)j * MS_THREADS + threadIdx.x, q1 - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t qi = qb + (uint64_t)j * MS_THREADS + threadIdx.x;
+                    const uint32_t e[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint64_t ri = 4 * qi + c;
+                        if (qi < q1 && ri >= lo && ri < hi) atomicAdd(&s_hist[narrow_region(b, e[c], lv.n_regions) - b * lv.nb], 1u);
+                    }
+                }
+            }
+        } else
         for (uint64_t base = lo; base < hi; base += 8ull * MS_THREADS) {
             uint64_t r[8];
 #pragma unroll
@@ -1281,6 +1302,7 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false
 // carve the scratch buffer for a batch of at most n_max records; n_tiles = 0 when the input is records
 static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins, bool allow_narrow = false) {
     plan_cfg(h, &p->cfg, allow_narrow);
+    n_max = (n_max + 7) & ~7ull;                                // every record array starts 16-byte aligned and has slack for vector loads
     p->two_level = p->cfg.g_shift != 0;
     p->fmt = p->cfg.narrow ? FMT_NARROW : FMT_PACK8;          // the caller switches to FMT_WIDE where it applies
     p->n_max = n_max; p->R = p->cfg.n_regions;
