@@ -21,7 +21,10 @@ namespace kq {
 constexpr uint64_t EMPTY_KEY = ~0ull;
 constexpr uint32_t LARGEST = 4294967295u;      // include/kreeq.h:68
 constexpr uint32_t LOW_TIER_MAX = 254;         // src/graph-builder.cpp:166: the 255th instance overflows
-constexpr int REGION_SHIFT = 11;
+#ifndef KQ_REGION_SHIFT
+#define KQ_REGION_SHIFT 11
+#endif
+constexpr int REGION_SHIFT = KQ_REGION_SHIFT;
 constexpr uint32_t REGION_SLOTS = 1u << REGION_SHIFT;   // 2048 slots x 24 B = 48 KiB: three region images per CU's LDS
 
 struct Slot { uint64_t key, edges8, cov; };
@@ -299,7 +302,7 @@ __device__ __forceinline__ void tile_load(const uint8_t* __restrict__ ab, int64_
 // prev/next = neighbouring base codes, or 4 when that neighbour is not a base of the same run.
 template <bool ALL, class F>
 __device__ __forceinline__ void lane_scan_core(const uint32_t* s_codes, const uint32_t* s_inv, int64_t lo_valid, uint64_t tile,
-                                               int k, F&& f) {
+                                               int k, F&& f, uint64_t range_lo = 0, uint64_t range_hi = ~0ull) {
     const int tid = threadIdx.x;
     const bool lane_has_work = tid < TILE_STARTS / 16;
     if (!ALL && !lane_has_work) return;
@@ -322,6 +325,14 @@ __device__ __forceinline__ void lane_scan_core(const uint32_t* s_codes, const ui
     const uint32_t inv_ahead = (uint32_t)(ms >> k) & 0xFFFFu;
     const uint32_t inv_lo = (uint32_t)ms & 0xFFFFu;
     int bad = __popcll(ms & wmask);
+    // starts outside [range_lo, range_hi) (caller positions) are reported invalid: one 16-bit mask per lane
+    // instead of two 64-bit compares per start
+    uint32_t rmask = 0xFFFFu;
+    {
+        const int64_t a = (int64_t)range_lo - p0, b = range_hi == ~0ull ? 16 : (int64_t)range_hi - p0;
+        const uint32_t lo_i = a <= 0 ? 0u : a >= 16 ? 16u : (uint32_t)a, hi_i = b <= 0 ? 0u : b >= 16 ? 16u : (uint32_t)b;
+        rmask = ((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u);
+    }
     const int top = 2 * k - 2;                  // where the entering base lands in fw (wave-uniform)
     const bool top_hi = top >= 32;
     const int top_sh = top_hi ? top - 32 : top;
@@ -329,7 +340,7 @@ __device__ __forceinline__ void lane_scan_core(const uint32_t* s_codes, const ui
     uint64_t rv = revcomp2(fw, k);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const bool valid = lane_has_work && bad == 0;
+        const bool valid = lane_has_work && bad == 0 && ((rmask >> i) & 1u);
         const uint32_t nraw = (ahead >> (2 * i)) & 3u;
         const uint32_t ninv = (inv_ahead >> i) & 1u;
         const uint32_t next = ninv ? 4u : nraw;
@@ -360,9 +371,8 @@ template <class F>
 __device__ __forceinline__ void tile_lane_scan_all(const uint32_t* s_codes, const uint32_t* s_inv, int64_t lo_valid, uint64_t tile,
                                                    int k, EmitRange er, F&& f) {
     lane_scan_core<true>(s_codes, s_inv, lo_valid, tile, k,
-                         [&](int i, bool valid, uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
-                             f(i, valid && pos >= er.lo && pos < er.hi, fw, rv, prev, next);
-                         });
+                         [&](int i, bool valid, uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) { f(i, valid, fw, rv, prev, next); },
+                         er.lo, er.hi);
 }
 
 // number of valid k-mer starts among this lane's 16

@@ -101,6 +101,9 @@ __device__ __forceinline__ uint32_t narrow_aux(uint64_t h, uint32_t idx6) { retu
 __device__ __forceinline__ uint64_t narrow_hash(uint32_t bucket, uint32_t main32, uint32_t aux) {
     return ((uint64_t)bucket << (64 - NARROW_CBITS)) | ((uint64_t)main32 << (32 - NARROW_CBITS)) | ((uint64_t)(aux & 3u) << (30 - NARROW_CBITS));
 }
+// a narrow record on its way through one multisplit round: u32 | bin << 32 | byte << 48
+__device__ __forceinline__ uint64_t narrow_word(uint32_t main32, uint32_t aux, uint32_t bin) { return (uint64_t)main32 | ((uint64_t)(bin | (aux << 16)) << 32); }
+__device__ __forceinline__ uint32_t narrow_word_bin(uint64_t w) { return (uint32_t)(w >> 32) & 0xFFFFu; }
 // region of a narrow record of bucket b: the top 32 hash bits are b's 8 bits over the top 24 of the u32
 __device__ __forceinline__ uint32_t narrow_region(uint32_t bucket, uint32_t main32, uint64_t n_regions) {
     return __umulhi((bucket << (32 - NARROW_CBITS)) | (main32 >> NARROW_CBITS), (uint32_t)n_regions);
@@ -116,7 +119,7 @@ struct MsShared {
     uint8_t  saux[FMT == FMT_WIDE ? MS_TILE : 8];    //  4 KiB   (WIDE records only)
     uint32_t hist[NBC];
     uint32_t loff[NBC];
-    unsigned long long gbase[NBC];
+    uint32_t gbase[NBC];                     // output cursors: a partition pass handles < 2^32 records (host-checked)
     uint32_t wave_sum[16];
 #ifdef KQ_MS_STAMPS
     unsigned long long stamp_last;
@@ -178,9 +181,11 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     __syncthreads();
     KQ_MS_STAMP(s, 1);                            // zero hist + barrier
     static_assert(THREADS * ITEMS <= MS_TILE, "round size");
+    // FMT_NARROW: rec[i] is the staged word itself (u32 | bin << 32 | byte << 48, narrow_word()); aux[] and
+    // bin[] are not read, which saves the caller 2 x ITEMS registers
     uint32_t rank[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) rank[i] = atomicAdd(&s.hist[bin[i]], 1u);
+    for (int i = 0; i < ITEMS; ++i) rank[i] = atomicAdd(&s.hist[FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i]], 1u);
     __syncthreads();
     KQ_MS_STAMP(s, 2);                            // rank atomics + barrier
     ms_scan<THREADS>(s, nb + 1);
@@ -190,9 +195,9 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] -= s.loff[b];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t p = s.loff[bin[i]] + rank[i];
+        const uint32_t p = s.loff[FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i]] + rank[i];
         if (FMT == FMT_NARROW) {
-            s.stage[p] = (rec[i] & 0xFFFFFFFFull) | ((uint64_t)bin[i] << 32) | ((uint64_t)aux[i] << 48);    // one 8-byte write, no sub-dword traffic
+            s.stage[p] = rec[i];                                        // one 8-byte write, no sub-dword traffic
         } else {
             s.stage[p] = rec[i];
             s.sbin[p] = (uint16_t)bin[i];
@@ -205,10 +210,11 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     // fully unrolled so that the LDS reads of all ITEMS positions are in flight together (a rolled
     // loop is a chain of three dependent LDS round trips per record)
     uint32_t cb[ITEMS];
-    uint64_t cg[ITEMS], cv[ITEMS];
+    uint32_t cg[ITEMS];
+    uint64_t cv[ITEMS];
     if (FMT == FMT_NARROW) {
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) { cv[it] = s.stage[tid + it * THREADS]; cb[it] = (uint32_t)(cv[it] >> 32) & 0xFFFFu; }
+        for (int it = 0; it < ITEMS; ++it) { cv[it] = s.stage[tid + it * THREADS]; cb[it] = narrow_word_bin(cv[it]); }
     } else {
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) { const uint32_t j = tid + it * THREADS; cb[it] = j < total ? s.sbin[j] : 0u; cv[it] = s.stage[j]; }

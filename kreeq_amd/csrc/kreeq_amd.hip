@@ -130,6 +130,13 @@ constexpr uint32_t P2_UNIT = 8 * MS_TILE;   // records per P2 work unit (never c
 __device__ __forceinline__ uint32_t p1_col(uint32_t vb, uint32_t g1) { return (vb % g1) * P1_F + vb / g1; }
 
 // P1 pass A: per-workgroup counts of coarse buckets -> M1[bin][column] (u64, bin-major)
+// BINMODE 0: generic p1_bin (owner split / map-range filter); 1: coarse bucket of the table region; 2: top hash
+// bits (narrow).  The specialised modes keep the 16 unrolled steps free of wave-uniform branches.
+template <int BINMODE>
+__device__ __forceinline__ uint32_t p1_bin_of(const PartCfg& cfg, uint64_t key, uint64_t h) {
+    return BINMODE == 2 ? (uint32_t)(h >> (64 - NARROW_CBITS)) : BINMODE == 1 ? (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift) : p1_bin(cfg, key, h);
+}
+template <int BINMODE>
 __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
                                                           PartCfg cfg, EmitRange er, uint32_t g1, unsigned long long* __restrict__ m1) {
     __shared__ uint32_t s_codes[TILE_THREADS];
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
         tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
             if (valid) {
                 const uint64_t key = fw < rv ? fw : rv;
-                const uint32_t b = p1_bin(cfg, key, table_hash(key, (uint32_t)k));
-                if (b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
+                const uint32_t b = p1_bin_of<BINMODE>(cfg, key, table_hash(key, (uint32_t)k));
+                if (BINMODE != 0 || b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
             }
         });
         __syncthreads();
@@ -162,7 +169,7 @@ __global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const un
     if (b == cfg.n_coarse) coarse_off[b] = *total;
 }
 // P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
-template <int FMT, int NBC>
+template <int FMT, int NBC, int BINMODE>
 __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 : 2) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
                                                              PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
                                                              uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
     const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
     const uint64_t n_tiles = n_tiles_of(lead, len);
     const uint64_t cols = (uint64_t)gridDim.x * P1_F;
-    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += MS_THREADS) s.gbase[b] = m1[(uint64_t)b * cols + (uint64_t)blockIdx.x * P1_F];
+    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += MS_THREADS) s.gbase[b] = (uint32_t)m1[(uint64_t)b * cols + (uint64_t)blockIdx.x * P1_F];
 #ifdef KQ_MS_STAMPS
     if (threadIdx.x == 0) s.stamp_on = 0;
 #endif
@@ -193,13 +200,12 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
                 const uint32_t e = edge_idx6(is_fw, prev, next);
                 aux[i] = aux_fmt == AUX_IDX6 ? e : idx6_to_edge_byte(e);
             } else if (NARROW) {
-                rec[i] = narrow_main(h);
-                aux[i] = narrow_aux(h, edge_idx6(is_fw, prev, next));
+                rec[i] = narrow_word(narrow_main(h), narrow_aux(h, edge_idx6(is_fw, prev, next)), valid ? p1_bin_of<BINMODE>(cfg, key, h) : cfg.n_coarse);
             } else {
                 rec[i] = rec_pack_hash(h, is_fw, prev, next);
                 aux[i] = 0;
             }
-            bin[i] = valid ? p1_bin(cfg, key, h) : cfg.n_coarse;
+            if (!NARROW) bin[i] = valid ? p1_bin_of<BINMODE>(cfg, key, h) : cfg.n_coarse;
         });
         block_multisplit<FMT>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux,
                                [&] { landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w); });   // ends with a barrier
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
         const uint32_t b = seg_of_unit(unit_base, lv.n_seg, u);
         const uint64_t lo = seg_off[b] + (u - unit_base[b]) * P2_UNIT;
         const uint64_t hi = lo + P2_UNIT < seg_off[b + 1] ? lo + P2_UNIT : seg_off[b + 1];
-        for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS) s.gbase[i] = group_base[(uint64_t)b * nb + i] + m2[u * nb + i];
+        for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS) s.gbase[i] = (uint32_t)(group_base[(uint64_t)b * nb + i] + m2[u * nb + i]);
 #ifdef KQ_MS_STAMPS
         if (threadIdx.x == 0) { s.stamp_on = 1; s.stamp_last = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -355,8 +361,8 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                 const uint64_t i = pos + (uint64_t)j * LV_THREADS + threadIdx.x;
                 rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.k) : nxt[j];      // raw keys become hashes at the first level
                 aux[j] = nxt_aux[j];
-                bin[j] = i >= hi ? nb : NARROW ? narrow_region(b, (uint32_t)rec[j], lv.n_regions) - b * nb
-                                               : level_bin(lv, b, hash_region(rec_hash<WIDE>(rec[j]), lv.n_regions));
+                if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : narrow_region(b, (uint32_t)rec[j], lv.n_regions) - b * nb);
+                else bin[j] = i >= hi ? nb : level_bin(lv, b, hash_region(rec_hash<WIDE>(rec[j]), lv.n_regions));
             }
 #pragma unroll
             for (int j = 0; j < LV_ITEMS; ++j) {
@@ -430,12 +436,17 @@ extern "C" int kq_debug_stamps(unsigned long long* out, int reset) {
 #else
 #define KQ_STAMP(i) do { } while (0)
 #endif
-constexpr int P3_THREADS = 512;        // three 48 KiB images per CU (24 waves): with records double-buffered and groups handed out by ticket, one more region in flight per CU beats 2 x 1024 threads (whole count job 2.64 vs 2.67 ms)
+#ifndef KQ_P3_THREADS
+#define KQ_P3_THREADS 512
+#define KQ_P3_OCC 6
+#define KQ_P3_PF 2
+#endif
+constexpr int P3_THREADS = KQ_P3_THREADS;        // three 48 KiB images per CU (24 waves): with records double-buffered and groups handed out by ticket, one more region in flight per CU beats 2 x 1024 threads (whole count job 2.64 vs 2.67 ms)
 // Two instantiations share the regions: HOT = false takes the ordinary ones (deep record prefetch, no
 // folding state: fits the 80 VGPRs that let three workgroups share a CU) and appends the skewed ones
 // to hot_list; HOT = true then walks that list with the folding loop.
 template <int FMT, bool HOT>
-__global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
+__global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
                                                               int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty,
                                                               unsigned long long* __restrict__ hot_list /*[0] = count, then region ids*/,
                                                               uint32_t narrow_rps /*FMT_NARROW: regions per top-bit bucket*/) {
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : 6) void k_count_regions(Table
         // walked, so the only wait sits at the top of an iteration on loads that had a whole group's walk
         // to land.  (A conditional load per record made the compiler wait vmcnt(0) right after issuing
         // the next prefetch: a full HBM latency per record, ~4k cycles.)
-        constexpr int PF = 2;
+        constexpr int PF = KQ_P3_PF;
         uint64_t nxt_rec[PF];
         uint32_t nxt_aux[PF];
         const uint64_t last = hi - 1;                                  // hi > lo here
@@ -1301,6 +1312,7 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false
 }
 // carve the scratch buffer for a batch of at most n_max records; n_tiles = 0 when the input is records
 static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins, bool allow_narrow = false) {
+    if (n_max >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "a partition pass handles fewer than 2^32 records (got %llu): slice the input", (unsigned long long)n_max);
     plan_cfg(h, &p->cfg, allow_narrow);
     n_max = (n_max + 7) & ~7ull;                                // every record array starts 16-byte aligned and has slack for vector loads
     p->two_level = p->cfg.g_shift != 0;
@@ -1358,15 +1370,21 @@ static void marks_reset(kq_handle* h) {
 
 static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er, uint64_t* out,
                    uint8_t* out_aux, int aux_fmt) {
-    hipLaunchKernelGGL(k_p1_hist, dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1);
+    // plain table split (no owner split, no map-range filter): branch-free bin functions
+    const bool plain = cfg.mode == 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;
+    const int binmode = !plain ? 0 : cfg.narrow ? 2 : 1;
+#define KQ_P1H(B) hipLaunchKernelGGL(k_p1_hist<B>, dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1)
+    if (binmode == 2) KQ_P1H(2); else if (binmode == 1) KQ_P1H(1); else KQ_P1H(0);
+#undef KQ_P1H
     scan_u64(h, p->m1, (uint64_t)cfg.n_coarse * p->g1 * P1_F, p->sums, p->total);
     hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, p->m1, p->total, cfg, p->g1, p->seg_off);
     mark(h, "k_p1_hist+scan");
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
-#define KQ_P1S(W, N) hipLaunchKernelGGL((k_p1_scatter<W, N>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt)
-    if (cfg.narrow)   { KQ_P1S(FMT_NARROW, 512); }                                                    // 256 buckets
-    else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512); else KQ_P1S(FMT_WIDE, NB_MAX); }
-    else              { if (small) KQ_P1S(FMT_PACK8, 512); else KQ_P1S(FMT_PACK8, NB_MAX); }
+#define KQ_P1S(W, N, B) hipLaunchKernelGGL((k_p1_scatter<W, N, B>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt)
+    if (cfg.narrow)   { if (plain) KQ_P1S(FMT_NARROW, 512, 2); else KQ_P1S(FMT_NARROW, 512, 0); }     // 256 buckets
+    else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512, 0); else KQ_P1S(FMT_WIDE, NB_MAX, 0); }
+    else if (plain)   { if (small) KQ_P1S(FMT_PACK8, 512, 1); else KQ_P1S(FMT_PACK8, NB_MAX, 1); }
+    else              { if (small) KQ_P1S(FMT_PACK8, 512, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 0); }
 #undef KQ_P1S
     mark(h, "k_p1_scatter");
 }
