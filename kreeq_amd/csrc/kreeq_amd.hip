@@ -505,16 +505,29 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
         // The image is read with workgroup-scope relaxed atomic loads on the __shared__ array itself: a
         // volatile access through a generic pointer compiles to flat_load + s_waitcnt vmcnt(0), which also
         // drains the record prefetches on every probe.
+        // Four slots of the probe sequence are read per LDS round trip: a wave needs the MAXIMUM probe count of
+        // its 64 lanes in dependent round trips (4-6 at load 0.5 when probing one slot at a time -- the walk
+        // was bound by exactly that latency chain), now a quarter of it.  The snapshot is scanned in order; an
+        // EMPTY slot is claimed with a CAS whose result decides (slots only ever go EMPTY -> key).
         auto find_slot = [&](uint64_t key, uint64_t h) -> uint32_t {
             const uint32_t off = hash_offset(h, t.k);
-            for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
-                const uint32_t w = 3u * ((off + probe) & (REGION_SLOTS - 1));
-                uint64_t cur = __hip_atomic_load(&s_img[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (cur == EMPTY_KEY) {
-                    cur = atomicCAS((unsigned long long*)&s_img[w], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-                    if (cur == EMPTY_KEY) { ++n_new; return w; }
+            for (uint32_t base = 0; base < REGION_SLOTS; base += 4) {
+                uint32_t w[4];
+                uint64_t c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w[j] = 3u * ((off + base + j) & (REGION_SLOTS - 1));
+                    c[j] = __hip_atomic_load(&s_img[w[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if (cur == key) return w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t cur = c[j];
+                    if (cur == EMPTY_KEY) {
+                        cur = atomicCAS((unsigned long long*)&s_img[w[j]], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                        if (cur == EMPTY_KEY) { ++n_new; return w[j]; }
+                    }
+                    if (cur == key) return w[j];
+                }
             }
             atomicOr(&t.st->err_table_full, 1u);
             return REGION_SLOTS * 3;
