@@ -50,6 +50,7 @@ struct LevelCfg {
     uint32_t in_raw;        // 1: the input records hold raw keys (kq_insert_records): this level mixes them
     uint32_t k;             // k-mer length (width of the table's mix), needed when in_raw
     uint32_t narrow;        // 1: FMT_NARROW records, segment b = hash-prefix bucket b owning regions [b * nb, (b + 1) * nb)
+    uint32_t top8;          // 1: one segment of packed records, bin = top NARROW_CBITS hash bits; the scatter writes narrow records
 };
 __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, uint64_t region) {
     return (uint32_t)(region >> lv.out_shift) - (lv.seg_shift >= 32 ? 0u : (b << (lv.seg_shift - lv.out_shift)));
@@ -95,6 +96,7 @@ __device__ __forceinline__ uint64_t rec_pack_hash(uint64_t h, bool is_fw, uint32
 //              low 2 bits of the u8, whose upper 6 bits are the edge indices.  5 bytes instead of 8 through
 //              three of the four record passes, and the level histogram reads only the u32 array.
 constexpr int FMT_PACK8 = 0, FMT_WIDE = 1, FMT_NARROW = 2;
+constexpr int FMT_PACK8_TO_NARROW = 3;      // k_lv_scatter only: packed records in, narrow records out (bins = hash prefix)
 constexpr uint32_t NARROW_CBITS = 8, NARROW_MAX_K = 21;
 __device__ __forceinline__ uint32_t narrow_main(uint64_t h) { return (uint32_t)(h >> (32 - NARROW_CBITS)); }
 __device__ __forceinline__ uint32_t narrow_aux(uint64_t h, uint32_t idx6) { return ((uint32_t)(h >> (30 - NARROW_CBITS)) & 3u) | (idx6 << 2); }

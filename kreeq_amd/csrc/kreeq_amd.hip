@@ -279,6 +279,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
             for (int j = 0; j < 8; ++j)
                 if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi) {
                     const uint32_t bin = FMT == FMT_NARROW ? narrow_region(b, (uint32_t)r[j], lv.n_regions) - b * lv.nb
+                        : (FMT == FMT_PACK8 && lv.top8) ? (uint32_t)(rec_hash<false>(r[j]) >> (64 - NARROW_CBITS))
                         : level_bin(lv, b, hash_region(lv.in_raw ? table_hash(r[j], lv.k) : rec_hash<FMT == FMT_WIDE>(r[j]), lv.n_regions));
                     atomicAdd(&s_hist[bin], 1u);
                 }
@@ -323,9 +324,10 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                                                            const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
                                                            const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out,
                                                            uint8_t* __restrict__ out_aux) {
-    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, HAS_AUX = FMT != FMT_PACK8;
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, CONVERT = FMT == FMT_PACK8_TO_NARROW, HAS_AUX = WIDE || NARROW;
+    constexpr int MS_FMT = CONVERT ? FMT_NARROW : FMT;                  // format of the records this kernel writes
     const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
-    __shared__ MsShared<NBC, FMT> s;
+    __shared__ MsShared<NBC, MS_FMT> s;
     const uint32_t nb = lv.nb;
     const uint64_t n_units = unit_base[lv.n_seg];
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
@@ -362,6 +364,10 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                 rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.k) : nxt[j];      // raw keys become hashes at the first level
                 aux[j] = nxt_aux[j];
                 if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : narrow_region(b, (uint32_t)rec[j], lv.n_regions) - b * nb);
+                else if (CONVERT) {
+                    const uint64_t hh = rec_hash<false>(rec[j]);
+                    rec[j] = narrow_word(narrow_main(hh), narrow_aux(hh, (uint32_t)(rec[j] >> REC_EDGE_SHIFT) & 63u), i >= hi ? nb : (uint32_t)(hh >> (64 - NARROW_CBITS)));
+                }
                 else bin[j] = i >= hi ? nb : level_bin(lv, b, hash_region(rec_hash<WIDE>(rec[j]), lv.n_regions));
             }
 #pragma unroll
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                 nxt[j] = NARROW ? (uint64_t)recs32[i] : recs[i];
                 nxt_aux[j] = HAS_AUX ? recs_aux[i] : 0;
             }
-            block_multisplit<FMT, LV_THREADS, LV_ITEMS>(s, rec, aux, bin, nb, out, out_aux, [&] {
+            block_multisplit<MS_FMT, LV_THREADS, LV_ITEMS>(s, rec, aux, bin, nb, out, out_aux, [&] {
 #pragma unroll
                 for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (HAS_AUX) landed(nxt_aux[j]); }
             });
@@ -1404,7 +1410,7 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
 // afterwards p->group_base[0..n_seg*nb] are the output offsets
 static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint64_t* in, const uint8_t* in_aux, uint64_t* out, uint8_t* out_aux) {
-    const int fmt = lv.narrow ? FMT_NARROW : in_aux != nullptr ? FMT_WIDE : FMT_PACK8;
+    const int fmt = lv.narrow ? FMT_NARROW : in_aux != nullptr ? FMT_WIDE : FMT_PACK8;       // input format; lv.top8: packed in, narrow out
     const uint64_t groups = (uint64_t)lv.n_seg * lv.nb;
     hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, lv, p->unit_base);
     // one workgroup per work unit (upper bound of the unit count; surplus workgroups exit at once):
@@ -1420,24 +1426,25 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     const bool small = lv.nb < 512;
 #define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
                                         p->seg_off, p->unit_base, p->m2, p->group_base, out, out_aux)
-    if (fmt == FMT_NARROW)    { if (small) KQ_LVS(FMT_NARROW, 512); else KQ_LVS(FMT_NARROW, NB_MAX); }
+    if (lv.top8)              { KQ_LVS(FMT_PACK8_TO_NARROW, 512); }
+    else if (fmt == FMT_NARROW) { if (small) KQ_LVS(FMT_NARROW, 512); else KQ_LVS(FMT_NARROW, NB_MAX); }
     else if (fmt == FMT_WIDE) { if (small) KQ_LVS(FMT_WIDE, 512); else KQ_LVS(FMT_WIDE, NB_MAX); }
     else                      { if (small) KQ_LVS(FMT_PACK8, 512); else KQ_LVS(FMT_PACK8, NB_MAX); }
 #undef KQ_LVS
     mark(h, "k_lv_scatter");
 }
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
-    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 0;
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     return lv;
 }
 // FMT_NARROW: 256 top-bit buckets -> their regions (bucket b owns regions [b * nb, (b + 1) * nb))
 static LevelCfg level_narrow(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1u << NARROW_CBITS; lv.nb = (uint32_t)(cfg.n_regions >> NARROW_CBITS);
-    lv.seg_shift = 0; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 1;
+    lv.seg_shift = 0; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 1; lv.top8 = 0;
     return lv;
 }
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
-    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0; lv.narrow = 0;
+    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     return lv;
 }
 static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint8_t* sorted_aux, int aux_fmt, const unsigned long long* base) {
@@ -1486,8 +1493,21 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
 // `raw`: d_recs holds raw keys (kq_insert_records); otherwise the records of kq_emit_packed_dev (table hashes)
 static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const uint8_t* d_aux, int aux_fmt, uint64_t n, bool raw) {
     PartPlan p;
-    int rc = plan_alloc(h, &p, n, 0, 1);
+    int rc = plan_alloc(h, &p, n, 0, 1, /*allow_narrow=*/!d_aux && !raw);
     if (rc) return rc;
+    if (p.fmt == FMT_NARROW) {
+        // packed records of kq_emit_packed_dev on a narrow-eligible table: the first level splits on the top 8 hash
+        // bits and writes 5-byte records, the rest is the narrow path of count_partitioned
+        hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, h->stream, p.seg_off, 0ull, (unsigned long long)n);
+        LevelCfg first = level_flat_to_coarse(p.cfg);
+        first.top8 = 1; first.nb = 1u << NARROW_CBITS;
+        run_level(h, &p, first, d_recs, nullptr, p.recs1, p.aux1);
+        HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)((1u << NARROW_CBITS) + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
+        run_level(h, &p, level_narrow(p.cfg), p.recs1, p.aux1, p.recs2, p.aux2);
+        run_p3(h, &p, p.recs2, p.aux2, AUX_IDX6, p.group_base);
+        HIPC(hipGetLastError());
+        return KQ_OK;
+    }
     if (d_aux) p.fmt = FMT_WIDE;
     uint8_t* a1 = d_aux ? p.aux1 : nullptr;
     uint8_t* a2 = d_aux ? p.aux2 : nullptr;

@@ -374,7 +374,7 @@ def _unpack_records(recs, k):
     return key, edge.astype(np.uint8)
 
 
-@pytest.mark.parametrize("k,hint", [(21, 0), (27, 4_000_000)])
+@pytest.mark.parametrize("k,hint", [(21, 0), (27, 4_000_000), (21, 5_000_000), (17, 3_100_000)])    # the last two: receive side converts to 5-byte records
 def test_packed_emit_exchange_insert(kq, O, k, hint):
     """multi-GPU staging with packed records on one GPU: owner split -> per-part insert (partitioned)"""
     import torch
