@@ -136,9 +136,12 @@ template <int BINMODE>
 __device__ __forceinline__ uint32_t p1_bin_of(const PartCfg& cfg, uint64_t key, uint64_t h) {
     return BINMODE == 2 ? (uint32_t)(h >> (64 - NARROW_CBITS)) : BINMODE == 1 ? (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift) : p1_bin(cfg, key, h);
 }
-template <int BINMODE>
-__global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+// KC != 0: k is the compile-time constant KC (the default k = 21 gets its own instantiation: every
+// k-dependent shift and mask of the 16 scan steps and of the hash folds to an immediate)
+template <int BINMODE, int KC>
+__global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k_arg,
                                                           PartCfg cfg, EmitRange er, uint32_t g1, unsigned long long* __restrict__ m1) {
+    const int k = KC ? KC : k_arg;
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
     __shared__ uint32_t s_hist[NB_MAX];
@@ -169,13 +172,14 @@ __global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const un
     if (b == cfg.n_coarse) coarse_off[b] = *total;
 }
 // P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
-template <int FMT, int NBC, int BINMODE>
-__global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 : 2) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+template <int FMT, int NBC, int BINMODE, int KC>
+__global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 : 2) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k_arg,
                                                              PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
                                                              uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
     constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW;
+    const int k = KC ? KC : k_arg;
     __shared__ MsShared<NBC, FMT> s;
     const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
     const uint64_t n_tiles = n_tiles_of(lead, len);
@@ -1392,18 +1396,18 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     // plain table split (no owner split, no map-range filter): branch-free bin functions
     const bool plain = cfg.mode == 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;
     const int binmode = !plain ? 0 : cfg.narrow ? 2 : 1;
-#define KQ_P1H(B) hipLaunchKernelGGL(k_p1_hist<B>, dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1)
-    if (binmode == 2) KQ_P1H(2); else if (binmode == 1) KQ_P1H(1); else KQ_P1H(0);
+#define KQ_P1H(B, K) hipLaunchKernelGGL((k_p1_hist<B, K>), dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1)
+    if (binmode == 2) { if (h->k == 21) KQ_P1H(2, 21); else KQ_P1H(2, 0); } else if (binmode == 1) KQ_P1H(1, 0); else KQ_P1H(0, 0);
 #undef KQ_P1H
     scan_u64(h, p->m1, (uint64_t)cfg.n_coarse * p->g1 * P1_F, p->sums, p->total);
     hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, p->m1, p->total, cfg, p->g1, p->seg_off);
     mark(h, "k_p1_hist+scan");
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
-#define KQ_P1S(W, N, B) hipLaunchKernelGGL((k_p1_scatter<W, N, B>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt)
-    if (cfg.narrow)   { if (plain) KQ_P1S(FMT_NARROW, 512, 2); else KQ_P1S(FMT_NARROW, 512, 0); }     // 256 buckets
-    else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512, 0); else KQ_P1S(FMT_WIDE, NB_MAX, 0); }
-    else if (plain)   { if (small) KQ_P1S(FMT_PACK8, 512, 1); else KQ_P1S(FMT_PACK8, NB_MAX, 1); }
-    else              { if (small) KQ_P1S(FMT_PACK8, 512, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 0); }
+#define KQ_P1S(W, N, B, K) hipLaunchKernelGGL((k_p1_scatter<W, N, B, K>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt)
+    if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1S(FMT_NARROW, 512, 2, 21); else if (plain) KQ_P1S(FMT_NARROW, 512, 2, 0); else KQ_P1S(FMT_NARROW, 512, 0, 0); }     // 256 buckets
+    else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512, 0, 0); else KQ_P1S(FMT_WIDE, NB_MAX, 0, 0); }
+    else if (plain)   { if (small) KQ_P1S(FMT_PACK8, 512, 1, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 1, 0); }
+    else              { if (small) KQ_P1S(FMT_PACK8, 512, 0, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 0, 0); }
 #undef KQ_P1S
     mark(h, "k_p1_scatter");
 }
