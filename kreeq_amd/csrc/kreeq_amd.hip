@@ -707,6 +707,85 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
     }
 }
 
+
+// K3 on partitioned records (counters only): the assembly's k-mers go through the same P1 / level split as
+// reads, then one workgroup per table region stages the region image in LDS (read-only) and evaluates its
+// records there -- sequential HBM traffic instead of one random 64-byte sector per k-mer.  A record holds
+// everything evaluateSegment needs (src/kreeq.cpp:145-216): the hash (-> key) and the indices of the
+// fw / bw edge the assembly continues with (edge_idx6: the strand mapping of :178-210 is already applied).
+template <int FMT>
+__global__ __launch_bounds__(P3_THREADS, 6) void k_lookup_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
+                                                                   const unsigned long long* __restrict__ region_base, uint32_t narrow_rps,
+                                                                   uint32_t cov_cutoff, unsigned long long* __restrict__ counters) {
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, HAS_AUX = FMT != FMT_PACK8;
+    const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
+    __shared__ uint64_t s_img[REGION_SLOTS * 3];
+    const int tid = threadIdx.x;
+    uint32_t missing = 0, total = 0, edge_missing = 0;
+    for (uint64_t r = blockIdx.x; r < t.n_regions; r += gridDim.x) {
+        const uint64_t lo = region_base[r], hi = region_base[r + 1];
+        if (lo == hi) continue;                                         // block-uniform
+        const uint4* gimg = reinterpret_cast<const uint4*>(t.slots + (r << REGION_SHIFT));
+        uint4* limg = reinterpret_cast<uint4*>(s_img);
+        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+        __syncthreads();
+        const uint32_t narrow_bucket = NARROW ? (uint32_t)r / narrow_rps : 0u;
+        const uint64_t last = hi - 1;
+        for (uint64_t base = lo; base < hi; base += 2ull * P3_THREADS) {
+            uint64_t rec[2];
+            uint32_t aux[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint64_t j = min(base + (uint64_t)q * P3_THREADS + tid, last);
+                rec[q] = NARROW ? (uint64_t)recs32[j] : recs[j];
+                aux[q] = HAS_AUX ? recs_aux[j] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (base + (uint64_t)q * P3_THREADS + tid >= hi) continue;
+                const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec[q], aux[q]) : rec_hash<WIDE>(rec[q]);
+                const uint64_t key = key_of_hash(h, t.k);
+                const uint32_t idx6 = NARROW ? aux[q] >> 2 : WIDE ? aux[q] : (uint32_t)(rec[q] >> REC_EDGE_SHIFT) & 63u;
+                const uint32_t off = hash_offset(h, t.k);
+                uint32_t found = REGION_SLOTS * 3;
+                for (uint32_t pb = 0; pb < REGION_SLOTS && found == REGION_SLOTS * 3; pb += 4) {     // :153, four slots per LDS round trip
+                    uint32_t w[4];
+                    uint64_t c[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { w[j] = 3u * ((off + pb + j) & (REGION_SLOTS - 1)); c[j] = s_img[w[j]]; }
+                    bool stop = false;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!stop && c[j] == key) { found = w[j]; stop = true; }
+                        if (!stop && c[j] == EMPTY_KEY) stop = true;
+                    }
+                    if (stop) break;
+                }
+                uint64_t cov = 0, e8 = 0;
+                const HcSlot* hs = nullptr;
+                if (found != REGION_SLOTS * 3) {
+                    e8 = s_img[found + 1]; cov = s_img[found + 2];
+                    if (cov > LOW_TIER_MAX) hs = hc_find(t, key);                                    // :156-166 (32-bit tier)
+                }
+                if (cov == 0 || cov < cov_cutoff) ++missing;                                         // :172-175
+                else {
+                    const uint32_t f = idx6 & 7u, b = (idx6 >> 3) & 7u;
+                    auto absent = [&](uint32_t e) { return ((e8 >> (8 * e)) & 0xFF) == 0 && !(hs && hs->cnt[e]); };
+                    if (f < 4 && b < 4 && absent(f) && absent(4 + b)) ++edge_missing;                 // :176-215
+                }
+                ++total;                                                                              // :216
+            }
+        }
+        __syncthreads();                                                // the next region overwrites the image
+    }
+    const uint64_t a = block_sum(missing), b = block_sum(total), c = block_sum(edge_missing);
+    if (threadIdx.x == 0) {                                                                           // :223-225
+        if (a) atomicAdd(&counters[0], (unsigned long long)a);
+        if (b) atomicAdd(&counters[1], (unsigned long long)b);
+        if (c) atomicAdd(&counters[2], (unsigned long long)c);
+    }
+}
+
 // K2 on explicit records: processBuffers :160-206
 __global__ __launch_bounds__(256) void k_insert_records(TableView t, const uint64_t* __restrict__ keys,
                                                          const uint8_t* __restrict__ edges, uint64_t n) {
@@ -976,6 +1055,7 @@ struct kq_handle {
     uint64_t kmers_bound = 0;        // upper bound of instances inserted (sizing the side table)
     uint64_t used_bound = 0;         // upper bound of occupied slots (skips the state read-back)
     bool table_empty = true;         // nothing inserted since kq_create / kq_clear
+    int lookup_path = 0;             // KQ_OPT_LOOKUP_PATH: 0 auto, 1 direct (k_lookup), 2 partitioned (k_lookup_regions)
     bool slots_dirty = false;        // the slot array is logically empty but its memory is not initialised yet (lazy clear)
     bool trust_capacity = false;     // KQ_OPT_TRUST_CAPACITY: capacity_hint bounds the distinct k-mers
     int count_path = 0;              // KQ_OPT_COUNT_PATH: 0 auto, 1 direct (global atomics), 2 partitioned
@@ -1253,6 +1333,9 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             if (lo >= hi || hi > h->map_count) return fail(KQ_ERR_INVALID, "map range [%lld,%lld) outside [0,%d]", (long long)lo, (long long)hi, h->map_count);
             h->filt_lo = (uint32_t)lo; h->filt_hi = (uint32_t)hi; return KQ_OK;
         }
+        case KQ_OPT_LOOKUP_PATH:
+            if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_LOOKUP_PATH must be 0, 1 or 2");
+            h->lookup_path = (int)value; return KQ_OK;
         case KQ_OPT_PROFILE: h->profile = value != 0; if (!h->profile) marks_reset(h); return KQ_OK;
         case KQ_OPT_SLICE_KMERS:
             if (value < 1) return fail(KQ_ERR_INVALID, "KQ_OPT_SLICE_KMERS must be positive");
@@ -1797,6 +1880,33 @@ int kq_histogram(kq_handle* h, uint64_t* cov, uint64_t* cnt, uint64_t cap, uint6
 }
 
 // ---- lookup ----------------------------------------------------------------------------------
+// K3 through the partition machinery (counters only): P1 -> (level) -> k_lookup_regions
+static int lookup_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er, uint32_t cov_cutoff,
+                              uint32_t map_lo, uint32_t map_hi, unsigned long long* d_counters) {
+    PartPlan p;
+    PartCfg c0; plan_cfg(h, &c0, true);
+    int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), c0.n_coarse, true);
+    if (rc) return rc;
+    const bool wide = h->k > PART_MAX_K;
+    if (wide) p.fmt = FMT_WIDE;
+    uint8_t* a1 = p.fmt != FMT_PACK8 ? p.aux1 : nullptr;
+    uint8_t* a2 = p.fmt != FMT_PACK8 ? p.aux2 : nullptr;
+    p.cfg.filt_lo = map_lo; p.cfg.filt_hi = map_hi;               // the reference's range filter, src/kreeq.cpp:150
+    run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
+    const uint64_t* sorted = p.recs1; const uint8_t* sorted_aux = a1; const unsigned long long* base = p.seg_off;
+    if (p.two_level) {
+        run_level(h, &p, p.fmt == FMT_NARROW ? level_narrow(p.cfg) : level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
+        sorted = p.recs2; sorted_aux = a2; base = p.group_base;
+    }
+    const uint32_t rps = p.fmt == FMT_NARROW ? (uint32_t)(p.R >> NARROW_CBITS) : 1u;
+    const dim3 grid((unsigned)std::min<uint64_t>(p.R, 1u << 30)), block(P3_THREADS);
+#define KQ_LK(F) hipLaunchKernelGGL((k_lookup_regions<F>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, base, rps, cov_cutoff, d_counters)
+    if (p.fmt == FMT_NARROW) KQ_LK(FMT_NARROW); else if (p.fmt == FMT_WIDE) KQ_LK(FMT_WIDE); else KQ_LK(FMT_PACK8);
+#undef KQ_LK
+    HIPC(hipGetLastError());
+    return KQ_OK;
+}
+
 int kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uint32_t cov_cutoff, uint16_t map_lo, uint16_t map_hi,
                            kq_dbgbase* d_per_base, uint64_t* d_counters) {
     if (!h || !d_counters || (!d_bases && len)) return fail(KQ_ERR_INVALID, "null argument");
@@ -1806,8 +1916,24 @@ int kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uint
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
     const uint32_t map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
-    const dim3 grid(grid_for(h, n_tiles_of(lead, len), 1));
     materialize(h);
+    // counters only, a sequence worth partitioning, and a table small enough next to it (the partitioned path
+    // streams the whole table once per slice): regions staged in LDS instead of one random sector per k-mer
+    const uint64_t kmers = len - h->k + 1;
+    if (!d_per_base && h->lookup_path != 1 && h->n_regions <= (1ull << 20) &&
+        (h->lookup_path == 2 || (kmers >= (1u << 20) && (double)h->n_slots() * sizeof(Slot) <= 64.0 * (double)std::min<uint64_t>(kmers, h->slice_kmers)))) {
+        for (uint64_t a = 0; a < kmers; a += h->slice_kmers) {
+            const uint64_t b = std::min(kmers, a + h->slice_kmers);
+            const uint64_t sub_off = a ? a - 1 : 0;
+            const uint64_t sub_len = std::min(len, b + h->k) - sub_off;
+            const uint8_t* sab; uint64_t slead;
+            aligned_view(d_bases + sub_off, &sab, &slead);
+            int rc = lookup_partitioned(h, sab, slead, sub_len, EmitRange{a - sub_off, b - sub_off}, cov_cutoff, map_lo, map_hi, (unsigned long long*)d_counters);
+            if (rc) return rc;
+        }
+        return KQ_OK;
+    }
+    const dim3 grid(grid_for(h, n_tiles_of(lead, len), 1));
     if (d_per_base) hipLaunchKernelGGL(k_lookup<true>, grid, dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len, h->k, (uint32_t)h->map_count,
                                        map_mask, (uint32_t)map_lo, (uint32_t)map_hi, cov_cutoff, d_per_base, (unsigned long long*)d_counters);
     else hipLaunchKernelGGL(k_lookup<false>, grid, dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len, h->k, (uint32_t)h->map_count,

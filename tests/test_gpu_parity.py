@@ -627,3 +627,35 @@ def test_narrow_records_hot_kmers_and_growth(kq, O):
     assert gpu.info()["slots_total"] > before and gpu.info()["slots_total"] % (256 * 2048) == 0
     assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
     assert H.entries_equal(gpu.export(), cpu.export())
+
+
+# ---------------------------------------------------------------------------------- partitioned lookup (K3)
+@pytest.mark.parametrize("k,hint", [(21, 5_000_000), (21, 0), (27, 4_000_000), (31, 5_000_000), (13, 3_000_000)])
+def test_partitioned_lookup_vs_oracle_and_direct(kq, O, k, hint):
+    """kq_lookup_sequence without per-base output through P1 -> level -> k_lookup_regions (every record format),
+    against the oracle's evaluateSegment restatement and the direct kernel: map ranges, coverage cut-off,
+    N runs, k-mers absent from the table, high-copy k-mers (edge counters in the side table)"""
+    reads, genome = H.synth_reads(30000, 150, 120000, seed=400 + k, err=0.01, n_rate=0.002)
+    rep = b"\n".join([b"ACGTTGCA" * 100] * 300)                      # cov and edges far beyond 255
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=hint), O.OracleDB(k, 128)
+    for b in (reads, rep):
+        gpu.count_batch(b)
+        cpu.count_batch(b, threads=8)
+    rng = np.random.default_rng(k)
+    asm = bytearray(genome + b"N" + b"ACGTTGCA" * 50 + b"NNN" + bytes(rng.choice(list(b"ACGT"), 30000).tolist()))
+    for pos in rng.integers(0, len(genome), 200):
+        asm[pos] = b"ACGT"[rng.integers(0, 4)]                       # assembly errors -> missing k-mers / edges
+    asm = bytes(asm)
+    for cutoff, lo, hi in ((0, 0, 128), (3, 0, 128), (0, 17, 90), (2, 100, 128)):
+        cc, _ = cpu.validate_sequence(asm, cov_cutoff=cutoff, map_lo=lo, map_hi=hi, threads=8)
+        gpu.set_option("lookup_path", "direct")
+        cd, _ = gpu.lookup_sequence(asm, cov_cutoff=cutoff, map_lo=lo, map_hi=hi)
+        gpu.set_option("lookup_path", "partitioned")
+        cp, _ = gpu.lookup_sequence(asm, cov_cutoff=cutoff, map_lo=lo, map_hi=hi)
+        assert np.array_equal(cd, cc), (cutoff, lo, hi)
+        assert np.array_equal(cp, cc), (cutoff, lo, hi)
+    # sliced sequence: k-mers and neighbours across a cut are evaluated exactly once
+    gpu.set_option("slice_kmers", 50021)
+    cp, _ = gpu.lookup_sequence(asm)
+    cc, _ = cpu.validate_sequence(asm, threads=8)
+    assert np.array_equal(cp, cc)
