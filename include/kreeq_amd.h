@@ -113,9 +113,11 @@ void* kq_get_stream(kq_handle* h);
  *                          kq_get_profile() returns "stage=ms;..." for the last batch (measurement aid)
  *   KQ_OPT_LOOKUP_PATH     kq_lookup_sequence(_dev) without per-base output: 0 = auto, 1 = direct (one table probe
  *                          per k-mer), 2 = partitioned (the k-mers are split by table region like read k-mers
- *                          and evaluated against region images staged in LDS) */
+ *                          and evaluated against region images staged in LDS)
+ *   KQ_OPT_MERGE_PATH      kq_merge into this handle: 0 = auto, 1 = one atomic add per source entry, 2 = region by
+ *                          region (destination images staged in LDS, both tables streamed once) */
 enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4, KQ_OPT_PROFILE = 5,
-       KQ_OPT_LOOKUP_PATH = 6 };
+       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7 };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_get_profile(kq_handle* h, char* buf, uint64_t cap);
 int  kq_sync(kq_handle* h);

@@ -213,11 +213,10 @@ __device__ __forceinline__ bool table_add(const TableView& t, uint64_t key, uint
 
 // logical (reference-visible) value of a slot: counters clamped to LARGEST
 struct Logical { uint32_t e[8]; uint32_t cov; };
-__device__ __forceinline__ Logical slot_logical(const TableView& t, const Slot* s) {
+__device__ __forceinline__ Logical logical_of(const TableView& t, uint64_t key, uint64_t e8, uint64_t cov) {
     Logical L;
-    uint64_t cov = s->cov, e8 = s->edges8;
     L.cov = cov > LARGEST ? LARGEST : (uint32_t)cov;
-    const HcSlot* hs = (cov > LOW_TIER_MAX) ? hc_find(t, s->key) : nullptr;
+    const HcSlot* hs = (cov > LOW_TIER_MAX) ? hc_find(t, key) : nullptr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         uint64_t v = (e8 >> (8 * e)) & 0xFF;
@@ -226,6 +225,7 @@ __device__ __forceinline__ Logical slot_logical(const TableView& t, const Slot* 
     }
     return L;
 }
+__device__ __forceinline__ Logical slot_logical(const TableView& t, const Slot* s) { return logical_of(t, s->key, s->edges8, s->cov); }
 
 // ---- sequence tile scanner ---------------------------------------------------------------------
 // One workgroup (256 threads) walks tiles of TILE_STARTS k-mer start positions.  Per tile it loads

@@ -847,6 +847,90 @@ __global__ __launch_bounds__(256) void k_merge(TableView dst, TableView src) {
         if (b) atomicAdd(&dst.st->kmers_added, (unsigned long long)b);
     }
 }
+// K4 by regions: dst += src without a global atomic per entry.  Both tables place a key by the same hash, so
+// the entries of dst region r can only come from the one or two (in general: a contiguous range of) src
+// regions that cover the same hash interval.  One workgroup per dst region: its image is staged in LDS
+// (or created there when dst is empty), the covering src regions are streamed, their entries that hash to r
+// are added with the rule of add_logical / table_add, and the image is written back.
+__global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, TableView src, int dst_is_empty) {
+    __shared__ uint64_t s_img[REGION_SLOTS * 3];
+    const int tid = threadIdx.x;
+    uint32_t n_new = 0;
+    uint64_t n_cov = 0;
+    for (uint64_t r = blockIdx.x; r < dst.n_regions; r += gridDim.x) {
+        uint4* gimg = reinterpret_cast<uint4*>(dst.slots + (r << REGION_SHIFT));
+        uint4* limg = reinterpret_cast<uint4*>(s_img);
+        if (dst_is_empty) {
+            for (int i = tid; i < (int)(REGION_SLOTS * 3); i += P3_THREADS) s_img[i] = (i % 3 == 0) ? EMPTY_KEY : 0ull;
+        } else {
+            for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+        }
+        __syncthreads();
+        // hash interval of dst region r (top 32 bits): [ceil(r 2^32 / R), ceil((r+1) 2^32 / R) - 1]
+        const uint64_t R = dst.n_regions;
+        const uint32_t h_lo = (uint32_t)(((r << 32) + R - 1) / R), h_hi = (uint32_t)((((r + 1) << 32) + R - 1) / R - 1);
+        const uint64_t s_lo = __umulhi(h_lo, (uint32_t)src.n_regions), s_hi = __umulhi(h_hi, (uint32_t)src.n_regions);
+        for (uint64_t sr = s_lo; sr <= s_hi; ++sr) {
+            const Slot* sslots = src.slots + (sr << REGION_SHIFT);
+            // the whole source region in flight at once (three 8-byte loads per slot, unconditional): a load behind
+            // the key test would cost two dependent memory round trips per slot
+            constexpr int SPT = REGION_SLOTS / P3_THREADS;
+            uint64_t sk[SPT], se[SPT], sc[SPT];
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) { const Slot* sp = sslots + tid + j * P3_THREADS; sk[j] = sp->key; se[j] = sp->edges8; sc[j] = sp->cov; }
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const uint64_t key = sk[j];
+                if (key == EMPTY_KEY) continue;
+                const uint64_t h = table_hash(key, dst.k);
+                if (hash_region(h, R) != r) continue;
+                const Logical L = logical_of(src, key, se[j], sc[j]);
+                uint64_t pack = 0;
+                bool fits = L.cov <= LOW_TIER_MAX, any = false;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (L.e[e] > LOW_TIER_MAX) fits = false; any |= L.e[e] != 0; pack |= (uint64_t)(L.e[e] & 0xFF) << (8 * e); }
+                // find-or-claim in the LDS image, four slots per round trip
+                const uint32_t off = hash_offset(h, dst.k);
+                uint32_t w = REGION_SLOTS * 3;
+                for (uint32_t pb = 0; pb < REGION_SLOTS && w == REGION_SLOTS * 3; pb += 4) {
+                    uint32_t ws[4];
+                    uint64_t c[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ws[j] = 3u * ((off + pb + j) & (REGION_SLOTS - 1)); c[j] = __hip_atomic_load(&s_img[ws[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (w != REGION_SLOTS * 3) break;
+                        uint64_t cur = c[j];
+                        if (cur == EMPTY_KEY) {
+                            cur = atomicCAS((unsigned long long*)&s_img[ws[j]], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                            if (cur == EMPTY_KEY) { ++n_new; w = ws[j]; break; }
+                        }
+                        if (cur == key) w = ws[j];
+                    }
+                }
+                if (w == REGION_SLOTS * 3) { atomicOr(&dst.st->err_table_full, 1u); continue; }
+                n_cov += L.cov;
+                const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], (unsigned long long)L.cov);
+                if (fits && old + L.cov <= LOW_TIER_MAX) {
+                    if (pack) atomicAdd((unsigned long long*)&s_img[w + 1], (unsigned long long)pack);
+                } else if (any) {                                       // beyond the u8 lanes: the wide counters (rare)
+                    HcSlot* hs = hc_upsert(dst, key);
+                    if (!hs) { atomicOr(&dst.st->err_hc_full, 1u); continue; }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (L.e[e]) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)L.e[e]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) gimg[i] = limg[i];
+        __syncthreads();
+    }
+    const uint64_t a = block_sum(n_new), b = block_sum(n_cov);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&dst.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&dst.st->kmers_added, (unsigned long long)b);
+    }
+}
 // rehash into a bigger table (growth): exact move of physical state
 __global__ __launch_bounds__(256) void k_rehash(TableView dst, const Slot* __restrict__ old, uint64_t n_old) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1055,6 +1139,7 @@ struct kq_handle {
     uint64_t kmers_bound = 0;        // upper bound of instances inserted (sizing the side table)
     uint64_t used_bound = 0;         // upper bound of occupied slots (skips the state read-back)
     bool table_empty = true;         // nothing inserted since kq_create / kq_clear
+    int merge_path = 0;              // KQ_OPT_MERGE_PATH (of the destination handle): 0 auto, 1 per-entry atomics, 2 region by region
     int lookup_path = 0;             // KQ_OPT_LOOKUP_PATH: 0 auto, 1 direct (k_lookup), 2 partitioned (k_lookup_regions)
     bool slots_dirty = false;        // the slot array is logically empty but its memory is not initialised yet (lazy clear)
     bool trust_capacity = false;     // KQ_OPT_TRUST_CAPACITY: capacity_hint bounds the distinct k-mers
@@ -1333,6 +1418,9 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             if (lo >= hi || hi > h->map_count) return fail(KQ_ERR_INVALID, "map range [%lld,%lld) outside [0,%d]", (long long)lo, (long long)hi, h->map_count);
             h->filt_lo = (uint32_t)lo; h->filt_hi = (uint32_t)hi; return KQ_OK;
         }
+        case KQ_OPT_MERGE_PATH:
+            if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_MERGE_PATH must be 0, 1 or 2");
+            h->merge_path = (int)value; return KQ_OK;
         case KQ_OPT_LOOKUP_PATH:
             if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_LOOKUP_PATH must be 0, 1 or 2");
             h->lookup_path = (int)value; return KQ_OK;
@@ -1986,6 +2074,16 @@ int kq_merge(kq_handle* dst, kq_handle* src) {
     if (rc) return rc;
     rc = reserve(dst, src->st_host->slots_used, src->st_host->kmers_added);
     if (rc) return rc;
+    // enough source entries to pay for streaming dst once: merge region by region in LDS; else per-entry atomics
+    if (dst->merge_path == 2 || (dst->merge_path == 0 && src->st_host->slots_used * 64 >= dst->n_slots())) {
+        const int empty = dst->table_empty ? 1 : 0;
+        hipLaunchKernelGGL(k_merge_regions, dim3((unsigned)std::min<uint64_t>(dst->n_regions, 1u << 30)), dim3(P3_THREADS), 0, dst->stream,
+                           dst->view(), src->view(), empty);
+        dst->slots_dirty = false;                       // every region image has been written
+        dst->table_empty = false;
+        HIPC(hipGetLastError());
+        return kq_sync(dst);
+    }
     dst->table_empty = false;
     materialize(dst);
     hipLaunchKernelGGL(k_merge, dim3(grid_for(dst, src->n_slots(), 256)), dim3(256), 0, dst->stream, dst->view(), src->view());

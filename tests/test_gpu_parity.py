@@ -659,3 +659,29 @@ def test_partitioned_lookup_vs_oracle_and_direct(kq, O, k, hint):
     cp, _ = gpu.lookup_sequence(asm)
     cc, _ = cpu.validate_sequence(asm, threads=8)
     assert np.array_equal(cp, cc)
+
+
+# ---------------------------------------------------------------------------------- union by regions (K4)
+@pytest.mark.parametrize("k,hint_dst,hint_src", [(21, 3_000_000, 3_000_000), (21, 9_000_000, 2_000_000), (21, 0, 4_000_000), (31, 2_500_000, 5_000_000)])
+def test_merge_by_regions(kq, O, k, hint_dst, hint_src):
+    """kq_merge region by region (tables of equal and of different geometry, destination empty / lazily cleared /
+    filled / growing, high-copy entries on either side) == per-entry atomic merge == oracle union"""
+    a, _ = H.synth_reads(25000, 150, 150000, seed=500 + k, err=0.01, n_rate=0.002)
+    b, _ = H.synth_reads(25000, 150, 150000, seed=501 + k, err=0.01)       # different genome: mostly new keys
+    rep = b"\n".join([b"GATTACA" * 120] * 200)
+    srcs = []
+    for batch in (a + b"\n" + rep, b, a + b"\n" + rep):                     # third: every key already present, cov sums pass 255
+        g = kq.KreeqDB(k, 128, capacity_hint=hint_src); g.count_batch(batch)
+        c = O.OracleDB(k, 128); c.count_batch(batch, threads=8)
+        srcs.append((g, c))
+    for path in ("partitioned", "direct"):
+        dst, ref = kq.KreeqDB(k, 128, capacity_hint=hint_dst), O.OracleDB(k, 128)
+        dst.set_option("merge_path", path)
+        junk, _ = H.synth_reads(2000, 100, 5000, seed=9)
+        dst.count_batch(junk); dst.clear()                                  # lazily cleared destination
+        for g, c in srcs:
+            dst.merge(g)
+            ref.merge(c)
+            assert dst.summary(with_hist=True) == ref.summary(with_hist=True), path
+        assert H.entries_equal(dst.export(), ref.export()), path
+        assert dst.info()["slots_used"] == ref.summary()["distinct"]
