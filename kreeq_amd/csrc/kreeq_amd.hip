@@ -1145,6 +1145,7 @@ struct kq_handle {
     bool trust_capacity = false;     // KQ_OPT_TRUST_CAPACITY: capacity_hint bounds the distinct k-mers
     int count_path = 0;              // KQ_OPT_COUNT_PATH: 0 auto, 1 direct (global atomics), 2 partitioned
     uint64_t slice_kmers = 1ull << 28;   // KQ_OPT_SLICE_KMERS
+    bool slice_user = false;             // set explicitly: no automatic enlargement
     uint32_t filt_lo = 0, filt_hi = 0;   // KQ_OPT_COUNT_MAP_RANGE (set to [0, map_count) at creation)
     bool profile = false;                // KQ_OPT_PROFILE: HIP events around the stages of the partitioned count
     std::vector<std::pair<const char*, hipEvent_t>> marks;
@@ -1427,7 +1428,7 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
         case KQ_OPT_PROFILE: h->profile = value != 0; if (!h->profile) marks_reset(h); return KQ_OK;
         case KQ_OPT_SLICE_KMERS:
             if (value < 1) return fail(KQ_ERR_INVALID, "KQ_OPT_SLICE_KMERS must be positive");
-            h->slice_kmers = (uint64_t)value; return KQ_OK;
+            h->slice_kmers = (uint64_t)value; h->slice_user = true; return KQ_OK;
         default: return fail(KQ_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -1710,7 +1711,16 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
     // a resident batch of any size is processed in slices of <= 2^28 k-mer starts (the partition
     // scratch is 16 B per start); a slice scans one extra base on the left and k on the right, so
     // k-mers and edges across a cut are seen exactly once
-    const uint64_t slice = h->slice_kmers;
+    // The partitioned path streams the whole table once per slice, so a slice should bring a few records per
+    // slot: with a large table (and memory to spare for 16 B of scratch per start) slices grow up to 2^31 starts
+    uint64_t slice = h->slice_kmers;
+    if (!h->slice_user && kmers > slice && 2 * h->n_slots() > slice) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t by_mem = (uint64_t)((free_b + h->part_bytes) / 24);          // 16 B scratch + margin per start
+            slice = std::max(slice, std::min<uint64_t>(std::min<uint64_t>(2 * h->n_slots(), 1ull << 31), by_mem));
+        }
+    }
     for (uint64_t a = 0; a < kmers; a += slice) {
         const uint64_t b = std::min(kmers, a + slice);
         int rc = reserve(h, b - a, b - a);
