@@ -268,6 +268,12 @@ struct Engine {
 
 uint64_t file_size(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0; }
 
+// Read-batch size handed to kq_count_batch: the partitioned count streams the table once per batch, so large
+// inputs (large tables) get batches of up to 1 GiB of bases; small inputs keep 128 MiB for parser/GPU overlap.
+static size_t batch_bytes_for(uint64_t input_bytes) {
+    const uint64_t lo = 128ull << 20, hi = 1ull << 30;
+    return (size_t)std::min(hi, std::max(lo, input_bytes / 16));
+}
 // Memory-bounded validate: the hash maps are processed in `passes` ranges, re-reading the reads for
 // every range -- the GPU counterpart of the reference's map-range loop (computeMapRange /
 // loadMapRange, src/kreeq.cpp:59-74) and of its spill-to-disk behaviour under -m.  Only 1/passes of
@@ -298,7 +304,7 @@ int run_passes(Engine& e) {
         if (p) kq_or_die(kq_clear(e.h));
         kq_or_die(kq_set_option(e.h, KQ_OPT_COUNT_MAP_RANGE, (int64_t)lo | ((int64_t)hi << 16)));
         for (auto& f : ui.inReads)
-            read_batches_parallel(f, (size_t)128 << 20, threads, [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
+            read_batches_parallel(f, batch_bytes_for(bytes), threads, [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
         kq_stats st;
         kq_or_die(kq_summary(e.h, &st));
         sum.total += st.total; sum.unique += st.unique; sum.distinct += st.distinct; sum.edges += st.edges;
@@ -344,7 +350,7 @@ int run(UserInput& ui) {
                 e.create(std::min<uint64_t>(bytes / 2 + (1 << 20), 1ull << 31));
                 verbose("Loading input reads.");
                 for (auto& f : ui.inReads)
-                    read_batches_parallel(f, (size_t)128 << 20, ui.maxThreads > 0 ? (unsigned)ui.maxThreads : std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
+                    read_batches_parallel(f, batch_bytes_for(bytes), ui.maxThreads > 0 ? (unsigned)ui.maxThreads : std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
                                           [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
                 verbose("Reads loaded.");
             } else {                                                 // Input::loadGraph, src/input.cpp:56-74
