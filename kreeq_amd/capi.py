@@ -127,9 +127,9 @@ class KreeqDB:
         self._h = C.c_void_p()
         _check(load().kq_create(C.byref(self._h), device, k, map_count, capacity_hint))
 
-    def close(self):
+    def close(self, _load=load):                 # bound at definition: module globals may be gone at interpreter exit
         if getattr(self, "_h", None):
-            load().kq_destroy(self._h)
+            _load().kq_destroy(self._h)
             self._h = None
 
     __del__ = close
