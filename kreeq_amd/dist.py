@@ -126,11 +126,11 @@ class ShardedCounter:
             for c in b"ACGTacgt":
                 is_base |= win == c
             sep = (~is_base).nonzero()
-            if sep.numel() == 0:
-                continue                                        # no separator nearby: make this chunk longer
-            cuts.append(lo + int(sep[0]) + 1)
+            # no separator nearby: this chunk stays empty and the next one is longer.  The number of chunks
+            # is ALWAYS n_chunks, so every rank issues the same number of collectives without having to agree
+            cuts.append(lo + int(sep[0]) + 1 if sep.numel() else cuts[-1])
         cuts.append(n)
-        return [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        return list(zip(cuts[:-1], cuts[1:]))
 
     def _exchange_start(self, payload, send_counts):
         """counts first (blocking, tiny), then one asynchronous all-to-all(v) per payload array"""
@@ -159,12 +159,7 @@ class ShardedCounter:
         # pipeline over chunks: the all-to-all of chunk i runs while chunk i-1 is inserted and chunk
         # i+1 is scanned (xGMI is point-to-point: the exchange costs about as much as the compute)
         n_total, pending = 0, None
-        chunks = self._cut_points(bases, self.n_chunks)
-        # every rank must issue the same number of collectives: agree on the largest chunk count and
-        # pad with empty chunks
-        nc = torch.tensor([len(chunks)], dtype=torch.int64, device=bases.device)
-        dist.all_reduce(nc, op=dist.ReduceOp.MAX, group=self.group)
-        chunks += [(0, 0)] * (int(nc.item()) - len(chunks))
+        chunks = self._cut_points(bases, self.n_chunks)          # exactly n_chunks (possibly empty) chunks on every rank
         for i, (lo, hi) in enumerate(chunks):
             # send buffer i % 2: the exchange of chunk i-2 was waited for before chunk i-1 was started
             payload, send_counts = self.engine.emit_partitioned(bases[lo:hi], self.world, slot=i % 2)
