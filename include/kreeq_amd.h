@@ -115,9 +115,11 @@ void* kq_get_stream(kq_handle* h);
  *                          per k-mer), 2 = partitioned (the k-mers are split by table region like read k-mers
  *                          and evaluated against region images staged in LDS)
  *   KQ_OPT_MERGE_PATH      kq_merge into this handle: 0 = auto, 1 = one atomic add per source entry, 2 = region by
- *                          region (destination images staged in LDS, both tables streamed once) */
+ *                          region (destination images staged in LDS, both tables streamed once)
+ *   KQ_OPT_NARROW_MID      (tuning / tests) regions per hash-prefix bucket from which the record split of the
+ *                          partitioned paths gets a middle level (default 2048, i.e. tables above 12.9 GB) */
 enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4, KQ_OPT_PROFILE = 5,
-       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7 };
+       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8 };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_get_profile(kq_handle* h, char* buf, uint64_t cap);
 int  kq_sync(kq_handle* h);

@@ -37,6 +37,7 @@ struct PartCfg {
     uint32_t filt_lo, filt_hi;   // count only k-mers whose map index key % map_count lies in [filt_lo, filt_hi)
     uint32_t raw_out;     // 1: WIDE records carry the raw key (kq_emit_partitioned_dev), else its table hash
     uint32_t narrow;      // 1: bin = top NARROW_CBITS hash bits (n_regions is a multiple of 2^NARROW_CBITS), FMT_NARROW records
+    uint32_t sub_bits;    // narrow: > 0 = a middle level cuts each bucket into 2^sub_bits sub-buckets first (very large tables)
 };
 
 // One level of the record split.  Input records are grouped in n_seg segments (seg_off[0..n_seg]);
@@ -51,6 +52,9 @@ struct LevelCfg {
     uint32_t k;             // k-mer length (width of the table's mix), needed when in_raw
     uint32_t narrow;        // 1: FMT_NARROW records, segment b = hash-prefix bucket b owning regions [b * nb, (b + 1) * nb)
     uint32_t top8;          // 1: one segment of packed records, bin = top NARROW_CBITS hash bits; the scatter writes narrow records
+    // narrow levels: segment b = (bucket b >> nr_shift, sub-bucket b & (2^nr_shift - 1)) starts at region
+    // bucket * nr_rps + sub * nr_sub; bin = (region - that) / nr_div (nr_inv = ceil(2^32 / nr_div))
+    uint32_t nr_shift, nr_rps, nr_sub, nr_div, nr_inv;
 };
 __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, uint64_t region) {
     return (uint32_t)(region >> lv.out_shift) - (lv.seg_shift >= 32 ? 0u : (b << (lv.seg_shift - lv.out_shift)));
@@ -109,6 +113,12 @@ __device__ __forceinline__ uint32_t narrow_word_bin(uint64_t w) { return (uint32
 // region of a narrow record of bucket b: the top 32 hash bits are b's 8 bits over the top 24 of the u32
 __device__ __forceinline__ uint32_t narrow_region(uint32_t bucket, uint32_t main32, uint64_t n_regions) {
     return __umulhi((bucket << (32 - NARROW_CBITS)) | (main32 >> NARROW_CBITS), (uint32_t)n_regions);
+}
+// bin of a narrow record (u32 part) of segment b in a narrow level
+__device__ __forceinline__ uint32_t narrow_bin(const LevelCfg& lv, uint32_t b, uint32_t main32) {
+    const uint32_t bucket = b >> lv.nr_shift, sub = b & ((1u << lv.nr_shift) - 1u);
+    const uint32_t x = narrow_region(bucket, main32, lv.n_regions) - (bucket * lv.nr_rps + sub * lv.nr_sub);
+    return lv.nr_div == 1 ? x : __umulhi(x, lv.nr_inv);             // exact: x * nr_div < 2^32
 }
 
 // LDS of one multisplit workgroup.  NBC = bin capacity (incl. the discard bin): 512 keeps the whole

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const uint64_t ri = 4 * qi + c;
-                        if (qi < q1 && ri >= lo && ri < hi) atomicAdd(&s_hist[narrow_region(b, e[c], lv.n_regions) - b * lv.nb], 1u);
+                        if (qi < q1 && ri >= lo && ri < hi) atomicAdd(&s_hist[narrow_bin(lv, b, e[c])], 1u);
                     }
                 }
             }
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi) {
-                    const uint32_t bin = FMT == FMT_NARROW ? narrow_region(b, (uint32_t)r[j], lv.n_regions) - b * lv.nb
+                    const uint32_t bin = FMT == FMT_NARROW ? narrow_bin(lv, b, (uint32_t)r[j])
                         : (FMT == FMT_PACK8 && lv.top8) ? (uint32_t)(rec_hash<false>(r[j]) >> (64 - NARROW_CBITS))
                         : level_bin(lv, b, hash_region(lv.in_raw ? table_hash(r[j], lv.k) : rec_hash<FMT == FMT_WIDE>(r[j]), lv.n_regions));
                     atomicAdd(&s_hist[bin], 1u);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                 const uint64_t i = pos + (uint64_t)j * LV_THREADS + threadIdx.x;
                 rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.k) : nxt[j];      // raw keys become hashes at the first level
                 aux[j] = nxt_aux[j];
-                if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : narrow_region(b, (uint32_t)rec[j], lv.n_regions) - b * nb);
+                if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : narrow_bin(lv, b, (uint32_t)rec[j]));
                 else if (CONVERT) {
                     const uint64_t hh = rec_hash<false>(rec[j]);
                     rec[j] = narrow_word(narrow_main(hh), narrow_aux(hh, (uint32_t)(rec[j] >> REC_EDGE_SHIFT) & 63u), i >= hi ? nb : (uint32_t)(hh >> (64 - NARROW_CBITS)));
@@ -1139,6 +1139,7 @@ struct kq_handle {
     uint64_t kmers_bound = 0;        // upper bound of instances inserted (sizing the side table)
     uint64_t used_bound = 0;         // upper bound of occupied slots (skips the state read-back)
     bool table_empty = true;         // nothing inserted since kq_create / kq_clear
+    uint32_t mid_rps = 2048;         // KQ_OPT_NARROW_MID: regions per hash-prefix bucket from which the split gets a middle level
     int merge_path = 0;              // KQ_OPT_MERGE_PATH (of the destination handle): 0 auto, 1 per-entry atomics, 2 region by region
     int lookup_path = 0;             // KQ_OPT_LOOKUP_PATH: 0 auto, 1 direct (k_lookup), 2 partitioned (k_lookup_regions)
     bool slots_dirty = false;        // the slot array is logically empty but its memory is not initialised yet (lazy clear)
@@ -1361,6 +1362,7 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
         uint64_t regions = (slots + REGION_SLOTS - 1) >> REGION_SHIFT;
         if (regions < 16) regions = 16;
         if (regions >= (uint64_t)NB_MAX) regions = (regions + 255) / 256 * 256;      // FMT_NARROW: 256 hash-prefix buckets of whole regions
+        if (regions >= (1ull << 19)) regions = (regions + 2047) / 2048 * 2048;         // ... of 8 sub-buckets of whole regions each
         rc = alloc_main(h, regions, &h->slots); if (rc) break;
         h->n_regions = regions;
         uint64_t hc = 1u << 16;
@@ -1419,6 +1421,9 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             if (lo >= hi || hi > h->map_count) return fail(KQ_ERR_INVALID, "map range [%lld,%lld) outside [0,%d]", (long long)lo, (long long)hi, h->map_count);
             h->filt_lo = (uint32_t)lo; h->filt_hi = (uint32_t)hi; return KQ_OK;
         }
+        case KQ_OPT_NARROW_MID:
+            if (value < 2 || value > (1 << 14)) return fail(KQ_ERR_INVALID, "KQ_OPT_NARROW_MID must be in [2, 16384]");
+            h->mid_rps = (uint32_t)value; return KQ_OK;
         case KQ_OPT_MERGE_PATH:
             if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_MERGE_PATH must be 0, 1 or 2");
             h->merge_path = (int)value; return KQ_OK;
@@ -1501,9 +1506,16 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false
     cfg->raw_out = 0;
     // 5-byte records (FMT_NARROW): first split on the top 8 hash bits, which needs every bucket to own a
     // whole number of regions (kq_create rounds large tables to a multiple of 256 regions; doubling keeps it)
-    cfg->narrow = allow_narrow && h->k <= (int)NARROW_MAX_K && cfg->g_shift != 0 && cfg->n_regions % (1u << NARROW_CBITS) == 0 &&
-                  (cfg->n_regions >> NARROW_CBITS) < (uint64_t)NB_MAX ? 1u : 0u;
-    if (cfg->narrow) cfg->n_coarse = 1u << NARROW_CBITS;
+    cfg->narrow = 0; cfg->sub_bits = 0;
+    if (allow_narrow && h->k <= (int)NARROW_MAX_K && cfg->n_regions >= (uint64_t)NB_MAX && cfg->n_regions % (1u << NARROW_CBITS) == 0) {
+        const uint64_t rps = cfg->n_regions >> NARROW_CBITS;
+        // one level bucket -> regions while a bucket has < mid_rps regions (the multisplit writes runs of 4096 / fan-out
+        // records), else a middle level of up to 8 sub-buckets: covers every table that fits the HBM (rps < 16384)
+        uint32_t sb = 0;
+        if (rps >= h->mid_rps) { sb = 3; while (sb > 0 && rps % (1u << sb)) --sb; }
+        if ((rps >> sb) < (uint64_t)NB_MAX && (sb > 0 || rps < (uint64_t)NB_MAX)) { cfg->narrow = 1; cfg->sub_bits = sb; }
+    }
+    if (cfg->narrow) { cfg->n_coarse = 1u << NARROW_CBITS; if (cfg->g_shift == 0) cfg->g_shift = 1; }
 }
 // carve the scratch buffer for a batch of at most n_max records; n_tiles = 0 when the input is records
 static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins, bool allow_narrow = false) {
@@ -1515,7 +1527,7 @@ static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tile
     p->n_max = n_max; p->R = p->cfg.n_regions;
     p->g1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (p1_bins < 512 ? 3 : 2)));
     p->m1_n = (uint64_t)p1_bins * p->g1 * P1_F;
-    const uint64_t nb_max = std::max<uint64_t>(std::max<uint64_t>(1ull << p->cfg.g_shift, p->cfg.n_coarse), p->cfg.narrow ? p->cfg.n_regions >> NARROW_CBITS : 0);
+    const uint64_t nb_max = std::max<uint64_t>(std::max<uint64_t>(1ull << p->cfg.g_shift, p->cfg.n_coarse), p->cfg.narrow ? (p->cfg.n_regions >> NARROW_CBITS) >> p->cfg.sub_bits : 0);
     p->m2_n = (n_max / P2_UNIT + NB_MAX + 2) * nb_max;         // u32 entries, enough for either level
     p->groups_n = std::max<uint64_t>(p->R, (uint64_t)p->cfg.n_coarse << p->cfg.g_shift) + 2;
     p->sums_n = std::max(p->m1_n, p->groups_n) / SCAN_CHUNK + 2;
@@ -1611,16 +1623,28 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
 }
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
+    lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
     return lv;
 }
 // FMT_NARROW: 256 top-bit buckets -> their regions (bucket b owns regions [b * nb, (b + 1) * nb))
-static LevelCfg level_narrow(const PartCfg& cfg) {
-    LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1u << NARROW_CBITS; lv.nb = (uint32_t)(cfg.n_regions >> NARROW_CBITS);
+// `sub_bits` > 0: a middle level first cuts every bucket into 2^sub_bits sub-buckets (tables of more than
+// 2048 regions per bucket: the last level then has 256 << sub_bits segments of rps >> sub_bits regions)
+static LevelCfg level_narrow(const PartCfg& cfg, uint32_t sub_bits = 0, bool middle = false) {
+    LevelCfg lv; lv.n_regions = cfg.n_regions;
+    const uint32_t rps = (uint32_t)(cfg.n_regions >> NARROW_CBITS), subsz = rps >> sub_bits;
     lv.seg_shift = 0; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 1; lv.top8 = 0;
+    lv.nr_rps = rps; lv.nr_sub = subsz;
+    if (middle) { lv.n_seg = 1u << NARROW_CBITS; lv.nb = 1u << sub_bits; lv.nr_shift = 0; lv.nr_div = subsz; }
+    else        { lv.n_seg = (1u << NARROW_CBITS) << sub_bits; lv.nb = subsz; lv.nr_shift = sub_bits; lv.nr_div = 1; }
+    lv.nr_inv = lv.nr_div > 1 ? (uint32_t)(((1ull << 32) + lv.nr_div - 1) / lv.nr_div) : 0;
     return lv;
 }
+// bucket -> regions for FMT_NARROW records, in one level or (large tables) two; afterwards `*sorted` holds the
+// records grouped by region and p->group_base their offsets
+static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux);
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
+    lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
     return lv;
 }
 static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint8_t* sorted_aux, int aux_fmt, const unsigned long long* base) {
@@ -1640,6 +1664,27 @@ static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint
     h->slots_dirty = false;          // every region has been written
 }
 
+// can the record split reach every region of this table?  (5-byte records: up to 256 x 8 x 2047 regions, i.e.
+// any table that fits the HBM; 8-byte / wide records: two fan-outs below NB_MAX)
+static bool part_table_ok(const kq_handle* h, bool narrow_possible) {
+    if (h->n_regions <= (1ull << 20)) return true;
+    if (!narrow_possible) return false;
+    PartCfg c; plan_cfg(h, &c, true);
+    return c.narrow != 0;
+}
+static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux) {
+    const uint32_t sb = p->cfg.sub_bits;
+    if (sb == 0) {
+        run_level(h, p, level_narrow(p->cfg), p->recs1, p->aux1, p->recs2, p->aux2);
+        *sorted = p->recs2; *sorted_aux = p->aux2;
+        return;
+    }
+    run_level(h, p, level_narrow(p->cfg, sb, true), p->recs1, p->aux1, p->recs2, p->aux2);
+    (void)hipMemcpyAsync(p->seg_off, p->group_base, (size_t)(((1u << NARROW_CBITS) << sb) + 1) * 8, hipMemcpyDeviceToDevice, h->stream);
+    run_level(h, p, level_narrow(p->cfg, sb, false), p->recs2, p->aux2, p->recs1, p->aux1);
+    *sorted = p->recs1; *sorted_aux = p->aux1;
+}
+
 // partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
 static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er) {
     PartPlan p;
@@ -1654,8 +1699,12 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     marks_reset(h);
     mark(h, "start");
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
-    if (p.two_level) {
-        run_level(h, &p, p.fmt == FMT_NARROW ? level_narrow(p.cfg) : level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
+    if (p.fmt == FMT_NARROW) {
+        const uint64_t* sorted; const uint8_t* sorted_aux;
+        run_narrow_levels(h, &p, &sorted, &sorted_aux);
+        run_p3(h, &p, sorted, sorted_aux, AUX_IDX6, p.group_base);
+    } else if (p.two_level) {
+        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
         run_p3(h, &p, p.recs2, a2, AUX_IDX6, p.group_base);
     } else {
         run_p3(h, &p, p.recs1, a1, AUX_IDX6, p.seg_off);       // bins were the regions themselves
@@ -1679,8 +1728,9 @@ static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const
         first.top8 = 1; first.nb = 1u << NARROW_CBITS;
         run_level(h, &p, first, d_recs, nullptr, p.recs1, p.aux1);
         HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)((1u << NARROW_CBITS) + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
-        run_level(h, &p, level_narrow(p.cfg), p.recs1, p.aux1, p.recs2, p.aux2);
-        run_p3(h, &p, p.recs2, p.aux2, AUX_IDX6, p.group_base);
+        const uint64_t* sorted; const uint8_t* sorted_aux;
+        run_narrow_levels(h, &p, &sorted, &sorted_aux);
+        run_p3(h, &p, sorted, sorted_aux, AUX_IDX6, p.group_base);
         HIPC(hipGetLastError());
         return KQ_OK;
     }
@@ -1733,11 +1783,11 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
         // partitioned path streams the whole table once per slice (2 x 24 B per slot) on top of ~37 B per
         // record; the atomic path costs ~95 ps per record whatever the table size (~480 B at the
         // part's streaming rate): partition unless the table is more than ~200 B per record of the slice
-        bool part = (b - a) >= (1u << 20) && h->n_regions <= (1ull << 20) &&     // both fan-outs < NB_MAX
+        bool part = (b - a) >= (1u << 20) && part_table_ok(h, true) &&
                     (double)h->n_slots() * sizeof(Slot) <= 200.0 * (double)(b - a);
         if (h->count_path == 1) part = false;
         if (h->count_path == 2) {
-            if (h->n_regions > (1ull << 20)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
+            if (!part_table_ok(h, true)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
             part = true;
         }
         if (part) {
@@ -1876,7 +1926,7 @@ int kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n) {
     if (!n) return KQ_OK;
     int rc = reserve(h, n, n);
     if (rc) return rc;
-    if (h->n_regions > (1ull << 20)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
+    if (!part_table_ok(h, true)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
     rc = count_partitioned_records(h, d_recs, nullptr, AUX_IDX6, n, false);
     h->table_empty = false;
     return rc;
@@ -1992,8 +2042,11 @@ static int lookup_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, ui
     p.cfg.filt_lo = map_lo; p.cfg.filt_hi = map_hi;               // the reference's range filter, src/kreeq.cpp:150
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
     const uint64_t* sorted = p.recs1; const uint8_t* sorted_aux = a1; const unsigned long long* base = p.seg_off;
-    if (p.two_level) {
-        run_level(h, &p, p.fmt == FMT_NARROW ? level_narrow(p.cfg) : level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
+    if (p.fmt == FMT_NARROW) {
+        run_narrow_levels(h, &p, &sorted, &sorted_aux);
+        base = p.group_base;
+    } else if (p.two_level) {
+        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
         sorted = p.recs2; sorted_aux = a2; base = p.group_base;
     }
     const uint32_t rps = p.fmt == FMT_NARROW ? (uint32_t)(p.R >> NARROW_CBITS) : 1u;
@@ -2018,7 +2071,7 @@ int kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uint
     // counters only, a sequence worth partitioning, and a table small enough next to it (the partitioned path
     // streams the whole table once per slice): regions staged in LDS instead of one random sector per k-mer
     const uint64_t kmers = len - h->k + 1;
-    if (!d_per_base && h->lookup_path != 1 && h->n_regions <= (1ull << 20) &&
+    if (!d_per_base && h->lookup_path != 1 && part_table_ok(h, true) &&
         (h->lookup_path == 2 || (kmers >= (1u << 20) && (double)h->n_slots() * sizeof(Slot) <= 64.0 * (double)std::min<uint64_t>(kmers, h->slice_kmers)))) {
         for (uint64_t a = 0; a < kmers; a += h->slice_kmers) {
             const uint64_t b = std::min(kmers, a + h->slice_kmers);

@@ -685,3 +685,33 @@ def test_merge_by_regions(kq, O, k, hint_dst, hint_src):
             assert dst.summary(with_hist=True) == ref.summary(with_hist=True), path
         assert H.entries_equal(dst.export(), ref.export()), path
         assert dst.info()["slots_used"] == ref.summary()["distinct"]
+
+
+@pytest.mark.parametrize("hint,mid", [(5_000_000, 2), (5_870_000, 4), (40_000_000, 16), (5_870_000, 2048)])
+def test_narrow_middle_level(kq, O, hint, mid):
+    """very large tables (>= 2048 regions per hash-prefix bucket) split bucket -> sub-bucket -> region; the
+    threshold is lowered here so that small tables take the same three-pass route (1, 2 and 3 sub-bucket bits),
+    through count, packed insert and the partitioned lookup"""
+    import torch
+
+    batch, genome = H.synth_reads(40000, 150, 200000, seed=611, err=0.01, n_rate=0.003)
+    gpu, cpu = kq.KreeqDB(21, 128, capacity_hint=hint), O.OracleDB(21, 128)
+    gpu.set_option("count_path", "partitioned")
+    gpu.set_option("narrow_mid", mid)
+    cut = batch.rfind(b"\n", 0, len(batch) // 2)
+    gpu.count_batch(batch[:cut])
+    cpu.count_batch(batch, threads=8)
+    # second half through the multi-GPU staging format (packed records -> converted -> narrow levels)
+    rest = batch[cut + 1:]
+    t = torch.frombuffer(bytearray(rest), dtype=torch.uint8).cuda()
+    recs = torch.empty(len(rest), dtype=torch.int64, device="cuda")
+    src = kq.KreeqDB(21, 128)
+    counts = src.emit_packed_dev(t.data_ptr(), len(rest), 1, recs.data_ptr(), len(rest))
+    gpu.insert_packed_dev(recs.data_ptr(), int(counts[0]))
+    gpu.sync()
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(gpu.export(), cpu.export())
+    gpu.set_option("lookup_path", "partitioned")
+    cg, _ = gpu.lookup_sequence(genome)
+    cc, _ = cpu.validate_sequence(genome, threads=8)
+    assert np.array_equal(cg, cc)
