@@ -715,3 +715,32 @@ def test_narrow_middle_level(kq, O, hint, mid):
     cg, _ = gpu.lookup_sequence(genome)
     cc, _ = cpu.validate_sequence(genome, threads=8)
     assert np.array_equal(cg, cc)
+
+
+def test_partitioned_paths_degenerate_inputs(kq, O):
+    """forced region-wise paths on inputs that bring nothing: sequences shorter than k / all N / empty,
+    an empty source or destination in kq_merge, an all-N read batch on the 5-byte count path"""
+    batch, genome = H.synth_reads(20000, 150, 80000, seed=700, err=0.01)
+    gpu, cpu = kq.KreeqDB(21, 128, capacity_hint=5_000_000), O.OracleDB(21, 128)
+    gpu.set_option("count_path", "partitioned")
+    gpu.set_option("lookup_path", "partitioned")
+    gpu.set_option("merge_path", "partitioned")
+    gpu.count_batch(b"N" * 500000)                                   # no valid k-mer at all
+    assert gpu.summary()["total"] == 0 and gpu.info()["slots_used"] == 0
+    for seq in (b"", b"ACGT", b"N" * 100000, b"ACGTACGTACGTACGTACGTA", genome[:20]):
+        c, _ = gpu.lookup_sequence(seq)
+        cc, _ = cpu.validate_sequence(seq)
+        assert np.array_equal(c, cc), seq[:30]
+    empty = kq.KreeqDB(21, 128, capacity_hint=5_000_000)
+    gpu.merge(empty)                                                 # empty into empty
+    assert gpu.summary()["total"] == 0
+    gpu.count_batch(batch)
+    cpu.count_batch(batch, threads=8)
+    gpu.merge(empty)                                                 # empty into filled
+    empty.set_option("merge_path", "partitioned")
+    empty.merge(gpu)                                                 # filled into empty
+    assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(empty.export(), cpu.export())
+    c, _ = empty.lookup_sequence(genome)
+    cc, _ = cpu.validate_sequence(genome, threads=8)
+    assert np.array_equal(c, cc)
