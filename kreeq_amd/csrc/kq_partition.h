@@ -102,6 +102,12 @@ __device__ __forceinline__ uint64_t rec_pack_hash(uint64_t h, bool is_fw, uint32
 constexpr int FMT_PACK8 = 0, FMT_WIDE = 1, FMT_NARROW = 2;
 constexpr int FMT_PACK8_TO_NARROW = 3;      // k_lv_scatter only: packed records in, narrow records out (bins = hash prefix)
 constexpr uint32_t NARROW_CBITS = 8, NARROW_MAX_K = 21;
+// FMT_TOP8 (k = 29..32 on a table with hash-prefix buckets): one u64 = the 56 hash bits below the bucket prefix,
+// left-aligned, | the two edge indices in the low 6 bits.  Replaces the 9-byte WIDE records on the count and
+// lookup paths; split levels and region kernels address it like a narrow record whose u32 is the top half.
+constexpr int FMT_TOP8 = 4;
+__device__ __forceinline__ uint64_t top8_rec(uint64_t h, uint32_t idx6) { return ((h << NARROW_CBITS) & ~63ull) | idx6; }
+__device__ __forceinline__ uint64_t top8_hash(uint32_t bucket, uint64_t rec) { return ((uint64_t)bucket << (64 - NARROW_CBITS)) | ((rec & ~63ull) >> NARROW_CBITS); }
 __device__ __forceinline__ uint32_t narrow_main(uint64_t h) { return (uint32_t)(h >> (32 - NARROW_CBITS)); }
 __device__ __forceinline__ uint32_t narrow_aux(uint64_t h, uint32_t idx6) { return ((uint32_t)(h >> (30 - NARROW_CBITS)) & 3u) | (idx6 << 2); }
 __device__ __forceinline__ uint64_t narrow_hash(uint32_t bucket, uint32_t main32, uint32_t aux) {

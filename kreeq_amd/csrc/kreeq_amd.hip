@@ -178,9 +178,10 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
                                                              uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
-    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW;
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8;
+    constexpr int MS_FMT = TOP8 ? FMT_PACK8 : FMT;                      // TOP8 records are single u64 words like packed ones
     const int k = KC ? KC : k_arg;
-    __shared__ MsShared<NBC, FMT> s;
+    __shared__ MsShared<NBC, MS_FMT> s;
     const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
     const uint64_t n_tiles = n_tiles_of(lead, len);
     const uint64_t cols = (uint64_t)gridDim.x * P1_F;
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
                 rec[i] = cfg.raw_out ? key : h;                             // raw keys only for kq_emit_partitioned_dev's caller
                 const uint32_t e = edge_idx6(is_fw, prev, next);
                 aux[i] = aux_fmt == AUX_IDX6 ? e : idx6_to_edge_byte(e);
+            } else if (TOP8) {
+                rec[i] = top8_rec(h, edge_idx6(is_fw, prev, next));
+                aux[i] = 0;
             } else if (NARROW) {
                 rec[i] = narrow_word(narrow_main(h), narrow_aux(h, edge_idx6(is_fw, prev, next)), valid ? p1_bin_of<BINMODE>(cfg, key, h) : cfg.n_coarse);
             } else {
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
             }
             if (!NARROW) bin[i] = valid ? p1_bin_of<BINMODE>(cfg, key, h) : cfg.n_coarse;
         });
-        block_multisplit<FMT>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux,
+        block_multisplit<MS_FMT>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux,
                                [&] { landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w); });   // ends with a barrier
     }
 }
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
             for (int j = 0; j < 8; ++j)
                 if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi) {
                     const uint32_t bin = FMT == FMT_NARROW ? narrow_bin(lv, b, (uint32_t)r[j])
+                        : FMT == FMT_TOP8 ? narrow_bin(lv, b, (uint32_t)(r[j] >> 32))
                         : (FMT == FMT_PACK8 && lv.top8) ? (uint32_t)(rec_hash<false>(r[j]) >> (64 - NARROW_CBITS))
                         : level_bin(lv, b, hash_region(lv.in_raw ? table_hash(r[j], lv.k) : rec_hash<FMT == FMT_WIDE>(r[j]), lv.n_regions));
                     atomicAdd(&s_hist[bin], 1u);
@@ -328,8 +333,8 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                                                            const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
                                                            const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out,
                                                            uint8_t* __restrict__ out_aux) {
-    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, CONVERT = FMT == FMT_PACK8_TO_NARROW, HAS_AUX = WIDE || NARROW;
-    constexpr int MS_FMT = CONVERT ? FMT_NARROW : FMT;                  // format of the records this kernel writes
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, CONVERT = FMT == FMT_PACK8_TO_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
+    constexpr int MS_FMT = CONVERT ? FMT_NARROW : TOP8 ? FMT_PACK8 : FMT;                  // format of the records this kernel writes
     const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
     __shared__ MsShared<NBC, MS_FMT> s;
     const uint32_t nb = lv.nb;
@@ -372,6 +377,7 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                     const uint64_t hh = rec_hash<false>(rec[j]);
                     rec[j] = narrow_word(narrow_main(hh), narrow_aux(hh, (uint32_t)(rec[j] >> REC_EDGE_SHIFT) & 63u), i >= hi ? nb : (uint32_t)(hh >> (64 - NARROW_CBITS)));
                 }
+                else if (TOP8) bin[j] = i >= hi ? nb : narrow_bin(lv, b, (uint32_t)(rec[j] >> 32));
                 else bin[j] = i >= hi ? nb : level_bin(lv, b, hash_region(rec_hash<WIDE>(rec[j]), lv.n_regions));
             }
 #pragma unroll
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
                                                               int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty,
                                                               unsigned long long* __restrict__ hot_list /*[0] = count, then region ids*/,
                                                               uint32_t narrow_rps /*FMT_NARROW: regions per top-bit bucket*/) {
-    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, HAS_AUX = FMT != FMT_PACK8;
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
     const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
     __shared__ unsigned long long s_new, s_kmers;
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
     for (uint64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
         const uint64_t r = HOT ? hot_list[1 + w] : w;
         const uint64_t lo = region_base[r], hi = region_base[r + 1];
-        const uint32_t narrow_bucket = NARROW ? (uint32_t)r / narrow_rps : 0u;
+        const uint32_t narrow_bucket = (NARROW || TOP8) ? (uint32_t)r / narrow_rps : 0u;
         if (lo == hi) {                                                 // block-uniform
             if (!HOT && table_is_empty == 2) {    // lazy kq_clear: this launch initialises every region, also the ones without records
                 ulonglong2* g2 = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
@@ -645,10 +651,10 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             const uint64_t rec = cur_rec[q];
             const uint32_t aux = cur_aux[q];
             uint64_t key = 0, pack = 0;
-            const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec, aux) : rec_hash<WIDE>(rec);
+            const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec, aux) : TOP8 ? top8_hash(narrow_bucket, rec) : rec_hash<WIDE>(rec);
             if (active) {
                 key = key_of_hash(h, t.k);                                   // the mix is a bijection: no key in the record
-                pack = NARROW ? idx6_to_pack(aux >> 2)
+                pack = NARROW ? idx6_to_pack(aux >> 2) : TOP8 ? idx6_to_pack((uint32_t)rec & 63u)
                      : WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
             }
             const uint64_t act = FOLD ? __ballot(active) : 0ull;
@@ -717,7 +723,7 @@ template <int FMT>
 __global__ __launch_bounds__(P3_THREADS, 6) void k_lookup_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
                                                                    const unsigned long long* __restrict__ region_base, uint32_t narrow_rps,
                                                                    uint32_t cov_cutoff, unsigned long long* __restrict__ counters) {
-    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, HAS_AUX = FMT != FMT_PACK8;
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
     const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
     const int tid = threadIdx.x;
@@ -729,7 +735,7 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_lookup_regions(TableView t, c
         uint4* limg = reinterpret_cast<uint4*>(s_img);
         for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
         __syncthreads();
-        const uint32_t narrow_bucket = NARROW ? (uint32_t)r / narrow_rps : 0u;
+        const uint32_t narrow_bucket = (NARROW || TOP8) ? (uint32_t)r / narrow_rps : 0u;
         const uint64_t last = hi - 1;
         for (uint64_t base = lo; base < hi; base += 2ull * P3_THREADS) {
             uint64_t rec[2];
@@ -743,9 +749,9 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_lookup_regions(TableView t, c
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 if (base + (uint64_t)q * P3_THREADS + tid >= hi) continue;
-                const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec[q], aux[q]) : rec_hash<WIDE>(rec[q]);
+                const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec[q], aux[q]) : TOP8 ? top8_hash(narrow_bucket, rec[q]) : rec_hash<WIDE>(rec[q]);
                 const uint64_t key = key_of_hash(h, t.k);
-                const uint32_t idx6 = NARROW ? aux[q] >> 2 : WIDE ? aux[q] : (uint32_t)(rec[q] >> REC_EDGE_SHIFT) & 63u;
+                const uint32_t idx6 = NARROW ? aux[q] >> 2 : TOP8 ? (uint32_t)rec[q] & 63u : WIDE ? aux[q] : (uint32_t)(rec[q] >> REC_EDGE_SHIFT) & 63u;
                 const uint32_t off = hash_offset(h, t.k);
                 uint32_t found = REGION_SLOTS * 3;
                 for (uint32_t pb = 0; pb < REGION_SLOTS && found == REGION_SLOTS * 3; pb += 4) {     // :153, four slots per LDS round trip
@@ -1507,7 +1513,7 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false
     // 5-byte records (FMT_NARROW): first split on the top 8 hash bits, which needs every bucket to own a
     // whole number of regions (kq_create rounds large tables to a multiple of 256 regions; doubling keeps it)
     cfg->narrow = 0; cfg->sub_bits = 0;
-    if (allow_narrow && h->k <= (int)NARROW_MAX_K && cfg->n_regions >= (uint64_t)NB_MAX && cfg->n_regions % (1u << NARROW_CBITS) == 0) {
+    if (allow_narrow && (h->k <= (int)NARROW_MAX_K || h->k > PART_MAX_K) && cfg->n_regions >= (uint64_t)NB_MAX && cfg->n_regions % (1u << NARROW_CBITS) == 0) {
         const uint64_t rps = cfg->n_regions >> NARROW_CBITS;
         // one level bucket -> regions while a bucket has < mid_rps regions (the multisplit writes runs of 4096 / fan-out
         // records), else a middle level of up to 8 sub-buckets: covers every table that fits the HBM (rps < 16384)
@@ -1523,7 +1529,7 @@ static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tile
     plan_cfg(h, &p->cfg, allow_narrow);
     n_max = (n_max + 7) & ~7ull;                                // every record array starts 16-byte aligned and has slack for vector loads
     p->two_level = p->cfg.g_shift != 0;
-    p->fmt = p->cfg.narrow ? FMT_NARROW : FMT_PACK8;          // the caller switches to FMT_WIDE where it applies
+    p->fmt = !p->cfg.narrow ? FMT_PACK8 : h->k > PART_MAX_K ? FMT_TOP8 : FMT_NARROW;      // the caller switches to FMT_WIDE where it applies
     p->n_max = n_max; p->R = p->cfg.n_regions;
     p->g1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (p1_bins < 512 ? 3 : 2)));
     p->m1_n = (uint64_t)p1_bins * p->g1 * P1_F;
@@ -1590,7 +1596,8 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     mark(h, "k_p1_hist+scan");
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
 #define KQ_P1S(W, N, B, K) hipLaunchKernelGGL((k_p1_scatter<W, N, B, K>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt)
-    if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1S(FMT_NARROW, 512, 2, 21); else if (plain) KQ_P1S(FMT_NARROW, 512, 2, 0); else KQ_P1S(FMT_NARROW, 512, 0, 0); }     // 256 buckets
+    if (cfg.narrow && h->k > PART_MAX_K) { if (plain && h->k == 31) KQ_P1S(FMT_TOP8, 512, 2, 31); else if (plain) KQ_P1S(FMT_TOP8, 512, 2, 0); else KQ_P1S(FMT_TOP8, 512, 0, 0); }
+    else if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1S(FMT_NARROW, 512, 2, 21); else if (plain) KQ_P1S(FMT_NARROW, 512, 2, 0); else KQ_P1S(FMT_NARROW, 512, 0, 0); }     // 256 buckets
     else if (out_aux && plain && h->k == 31) { if (small) KQ_P1S(FMT_WIDE, 512, 1, 31); else KQ_P1S(FMT_WIDE, NB_MAX, 1, 31); }   // the HiFi k
     else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512, 0, 0); else KQ_P1S(FMT_WIDE, NB_MAX, 0, 0); }
     else if (plain)   { if (small) KQ_P1S(FMT_PACK8, 512, 1, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 1, 0); }
@@ -1601,13 +1608,14 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
 // afterwards p->group_base[0..n_seg*nb] are the output offsets
 static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint64_t* in, const uint8_t* in_aux, uint64_t* out, uint8_t* out_aux) {
-    const int fmt = lv.narrow ? FMT_NARROW : in_aux != nullptr ? FMT_WIDE : FMT_PACK8;       // input format; lv.top8: packed in, narrow out
+    const int fmt = lv.narrow == 2 ? FMT_TOP8 : lv.narrow ? FMT_NARROW : in_aux != nullptr ? FMT_WIDE : FMT_PACK8;       // input format; lv.top8: packed in, narrow out
     const uint64_t groups = (uint64_t)lv.n_seg * lv.nb;
     hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, lv, p->unit_base);
     // one workgroup per work unit (upper bound of the unit count; surplus workgroups exit at once):
     // the hardware dispatcher balances them, a fixed grid looping over units left a 30 % tail
     const unsigned unit_grid = (unsigned)std::min<uint64_t>(p->n_max / P2_UNIT + lv.n_seg + 1, 1u << 30);
-    if (fmt == FMT_NARROW) hipLaunchKernelGGL(k_lv_hist<FMT_NARROW>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    if (fmt == FMT_TOP8) hipLaunchKernelGGL(k_lv_hist<FMT_TOP8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    else if (fmt == FMT_NARROW) hipLaunchKernelGGL(k_lv_hist<FMT_NARROW>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     else if (fmt == FMT_WIDE) hipLaunchKernelGGL(k_lv_hist<FMT_WIDE>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     else hipLaunchKernelGGL(k_lv_hist<FMT_PACK8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
@@ -1618,6 +1626,7 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
 #define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
                                         p->seg_off, p->unit_base, p->m2, p->group_base, out, out_aux)
     if (lv.top8)              { KQ_LVS(FMT_PACK8_TO_NARROW, 512); }
+    else if (fmt == FMT_TOP8) { if (small) KQ_LVS(FMT_TOP8, 512); else KQ_LVS(FMT_TOP8, NB_MAX); }
     else if (fmt == FMT_NARROW) { if (small) KQ_LVS(FMT_NARROW, 512); else KQ_LVS(FMT_NARROW, NB_MAX); }
     else if (fmt == FMT_WIDE) { if (small) KQ_LVS(FMT_WIDE, 512); else KQ_LVS(FMT_WIDE, NB_MAX); }
     else                      { if (small) KQ_LVS(FMT_PACK8, 512); else KQ_LVS(FMT_PACK8, NB_MAX); }
@@ -1632,10 +1641,10 @@ static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
 // FMT_NARROW: 256 top-bit buckets -> their regions (bucket b owns regions [b * nb, (b + 1) * nb))
 // `sub_bits` > 0: a middle level first cuts every bucket into 2^sub_bits sub-buckets (tables of more than
 // 2048 regions per bucket: the last level then has 256 << sub_bits segments of rps >> sub_bits regions)
-static LevelCfg level_narrow(const PartCfg& cfg, uint32_t sub_bits = 0, bool middle = false) {
+static LevelCfg level_narrow(const PartCfg& cfg, uint32_t sub_bits = 0, bool middle = false, bool top8_records = false) {
     LevelCfg lv; lv.n_regions = cfg.n_regions;
     const uint32_t rps = (uint32_t)(cfg.n_regions >> NARROW_CBITS), subsz = rps >> sub_bits;
-    lv.seg_shift = 0; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 1; lv.top8 = 0;
+    lv.seg_shift = 0; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = top8_records ? 2 : 1; lv.top8 = 0;
     lv.nr_rps = rps; lv.nr_sub = subsz;
     if (middle) { lv.n_seg = 1u << NARROW_CBITS; lv.nb = 1u << sub_bits; lv.nr_shift = 0; lv.nr_div = subsz; }
     else        { lv.n_seg = (1u << NARROW_CBITS) << sub_bits; lv.nb = subsz; lv.nr_shift = sub_bits; lv.nr_div = 1; }
@@ -1656,11 +1665,12 @@ static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint
     (void)hipMemsetAsync(hot, 0, 8, h->stream);
     const dim3 grid((unsigned)std::min<uint64_t>(p->R, 1u << 30)), grid_hot(h->n_cu), block(P3_THREADS);   // one workgroup per region: dispatcher-balanced
     const int empty = h->table_empty ? (h->slots_dirty ? 2 : 1) : 0;       // 2: also write the image of regions without records
-    const uint32_t rps = p->fmt == FMT_NARROW ? (uint32_t)(p->R >> NARROW_CBITS) : 1u;
+    const uint32_t rps = (p->fmt == FMT_NARROW || p->fmt == FMT_TOP8) ? (uint32_t)(p->R >> NARROW_CBITS) : 1u;
 #define KQ_P3(F) do { \
         hipLaunchKernelGGL((k_count_regions<F, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot, rps); \
         hipLaunchKernelGGL((k_count_regions<F, true>), grid_hot, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot, rps); } while (0)
     if (p->fmt == FMT_NARROW) KQ_P3(FMT_NARROW);
+    else if (p->fmt == FMT_TOP8) KQ_P3(FMT_TOP8);
     else if (sorted_aux) KQ_P3(FMT_WIDE);
     else KQ_P3(FMT_PACK8);
 #undef KQ_P3
@@ -1677,15 +1687,18 @@ static bool part_table_ok(const kq_handle* h, bool narrow_possible) {
 }
 static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux) {
     const uint32_t sb = p->cfg.sub_bits;
+    const bool t8 = p->fmt == FMT_TOP8;
+    uint8_t* a1 = t8 ? nullptr : p->aux1;
+    uint8_t* a2 = t8 ? nullptr : p->aux2;
     if (sb == 0) {
-        run_level(h, p, level_narrow(p->cfg), p->recs1, p->aux1, p->recs2, p->aux2);
-        *sorted = p->recs2; *sorted_aux = p->aux2;
+        run_level(h, p, level_narrow(p->cfg, 0, false, t8), p->recs1, a1, p->recs2, a2);
+        *sorted = p->recs2; *sorted_aux = a2;
         return;
     }
-    run_level(h, p, level_narrow(p->cfg, sb, true), p->recs1, p->aux1, p->recs2, p->aux2);
+    run_level(h, p, level_narrow(p->cfg, sb, true, t8), p->recs1, a1, p->recs2, a2);
     (void)hipMemcpyAsync(p->seg_off, p->group_base, (size_t)(((1u << NARROW_CBITS) << sb) + 1) * 8, hipMemcpyDeviceToDevice, h->stream);
-    run_level(h, p, level_narrow(p->cfg, sb, false), p->recs2, p->aux2, p->recs1, p->aux1);
-    *sorted = p->recs1; *sorted_aux = p->aux1;
+    run_level(h, p, level_narrow(p->cfg, sb, false, t8), p->recs2, a2, p->recs1, a1);
+    *sorted = p->recs1; *sorted_aux = a1;
 }
 
 // partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
@@ -1694,15 +1707,17 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     PartCfg c0; plan_cfg(h, &c0, true);
     int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), c0.n_coarse, true);
     if (rc) return rc;
-    const bool wide = h->k > PART_MAX_K;                       // 5-byte records up to k = 21 (large tables), 8-byte packed up to k = 28, hash + edge byte above
-    if (wide) p.fmt = FMT_WIDE;
-    uint8_t* a1 = p.fmt != FMT_PACK8 ? p.aux1 : nullptr;
-    uint8_t* a2 = p.fmt != FMT_PACK8 ? p.aux2 : nullptr;
+    // 5-byte records up to k = 21 and 8-byte hash-remainder records above k = 28 (tables with hash-prefix buckets),
+    // 8-byte packed records up to k = 28, hash + edge byte otherwise
+    if (h->k > PART_MAX_K && p.fmt != FMT_TOP8) p.fmt = FMT_WIDE;
+    const bool has_aux = p.fmt == FMT_WIDE || p.fmt == FMT_NARROW;
+    uint8_t* a1 = has_aux ? p.aux1 : nullptr;
+    uint8_t* a2 = has_aux ? p.aux2 : nullptr;
     p.cfg.filt_lo = h->filt_lo; p.cfg.filt_hi = h->filt_hi;      // KQ_OPT_COUNT_MAP_RANGE
     marks_reset(h);
     mark(h, "start");
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
-    if (p.fmt == FMT_NARROW) {
+    if (p.fmt == FMT_NARROW || p.fmt == FMT_TOP8) {
         const uint64_t* sorted; const uint8_t* sorted_aux;
         run_narrow_levels(h, &p, &sorted, &sorted_aux);
         run_p3(h, &p, sorted, sorted_aux, AUX_IDX6, p.group_base);
@@ -2038,24 +2053,24 @@ static int lookup_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, ui
     PartCfg c0; plan_cfg(h, &c0, true);
     int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), c0.n_coarse, true);
     if (rc) return rc;
-    const bool wide = h->k > PART_MAX_K;
-    if (wide) p.fmt = FMT_WIDE;
-    uint8_t* a1 = p.fmt != FMT_PACK8 ? p.aux1 : nullptr;
-    uint8_t* a2 = p.fmt != FMT_PACK8 ? p.aux2 : nullptr;
+    if (h->k > PART_MAX_K && p.fmt != FMT_TOP8) p.fmt = FMT_WIDE;
+    const bool has_aux = p.fmt == FMT_WIDE || p.fmt == FMT_NARROW;
+    uint8_t* a1 = has_aux ? p.aux1 : nullptr;
+    uint8_t* a2 = has_aux ? p.aux2 : nullptr;
     p.cfg.filt_lo = map_lo; p.cfg.filt_hi = map_hi;               // the reference's range filter, src/kreeq.cpp:150
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
     const uint64_t* sorted = p.recs1; const uint8_t* sorted_aux = a1; const unsigned long long* base = p.seg_off;
-    if (p.fmt == FMT_NARROW) {
+    if (p.fmt == FMT_NARROW || p.fmt == FMT_TOP8) {
         run_narrow_levels(h, &p, &sorted, &sorted_aux);
         base = p.group_base;
     } else if (p.two_level) {
         run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
         sorted = p.recs2; sorted_aux = a2; base = p.group_base;
     }
-    const uint32_t rps = p.fmt == FMT_NARROW ? (uint32_t)(p.R >> NARROW_CBITS) : 1u;
+    const uint32_t rps = (p.fmt == FMT_NARROW || p.fmt == FMT_TOP8) ? (uint32_t)(p.R >> NARROW_CBITS) : 1u;
     const dim3 grid((unsigned)std::min<uint64_t>(p.R, 1u << 30)), block(P3_THREADS);
 #define KQ_LK(F) hipLaunchKernelGGL((k_lookup_regions<F>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, base, rps, cov_cutoff, d_counters)
-    if (p.fmt == FMT_NARROW) KQ_LK(FMT_NARROW); else if (p.fmt == FMT_WIDE) KQ_LK(FMT_WIDE); else KQ_LK(FMT_PACK8);
+    if (p.fmt == FMT_NARROW) KQ_LK(FMT_NARROW); else if (p.fmt == FMT_TOP8) KQ_LK(FMT_TOP8); else if (p.fmt == FMT_WIDE) KQ_LK(FMT_WIDE); else KQ_LK(FMT_PACK8);
 #undef KQ_LK
     HIPC(hipGetLastError());
     return KQ_OK;

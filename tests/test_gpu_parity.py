@@ -333,7 +333,7 @@ def test_partitioned_high_copy_and_mixed_paths(kq, O):
     assert H.entries_equal(gpu.export(), cpu.export())
 
 
-@pytest.mark.parametrize("k,hint", [(29, 0), (31, 5_000_000), (32, 0)])
+@pytest.mark.parametrize("k,hint", [(29, 0), (31, 5_000_000), (32, 0), (32, 5_870_000), (29, 40_000_000)])   # large hints: 8-byte hash-remainder records
 def test_partitioned_wide_records(kq, O, k, hint):
     """k = 29..32: the key fills the u64, edges travel in a parallel byte array through the splits"""
     batch, genome = H.synth_reads(25000, 150, 70000, seed=60 + k, err=0.01, n_rate=0.003)
