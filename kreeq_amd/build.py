@@ -13,7 +13,7 @@ LIB = os.path.join(PKG, "lib", "libkreeq_amd.so")
 CLI = os.path.join(PKG, "bin", "kreeq")
 
 HIP_SOURCES = [os.path.join(PKG, "csrc", "kreeq_amd.hip")]
-HIP_DEPS = HIP_SOURCES + [os.path.join(PKG, "csrc", "kq_device.h"), os.path.join(ROOT, "include", "kreeq_amd.h")]
+HIP_DEPS = HIP_SOURCES + [os.path.join(PKG, "csrc", f) for f in ("kq_device.h", "kq_partition.h", "kq_kernels.h")] + [os.path.join(ROOT, "include", "kreeq_amd.h")]
 HOST_DIR = os.path.join(PKG, "host")
 
 

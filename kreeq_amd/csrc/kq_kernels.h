@@ -1,0 +1,1106 @@
+// Device kernels of libkreeq_amd (gfx950): the partitioned count path (P1 tile scan + multisplit, split levels,
+// k_count_regions), the region-wise lookup and union, and the table kernels (direct count, insert, import,
+// rehash, clear, summary, export, direct lookup).  Included by kreeq_amd.hip only; see DESIGN.md §4.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "../../include/kreeq_amd.h"
+#include "kq_device.h"
+#include "kq_partition.h"
+
+using namespace kq;
+
+// ================================================================================================
+// kernels
+// ================================================================================================
+
+// K1+K2 fused: hashSequences (src/graph-builder.cpp:75-113) + processBuffers (:160-206) without
+// materialising the 9-byte records: 1 B/base streamed in, random RMW on the table.
+__global__ __launch_bounds__(TILE_THREADS) void k_count_direct(TableView t, const uint8_t* __restrict__ ab,
+                                                                uint64_t lead, uint64_t len, int k, EmitRange er, PartCfg filt) {
+    uint32_t n_new = 0;
+    uint64_t n_kmers = 0;
+    scan_tiles(ab, lead, len, k, [&](uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+        if (pos < er.lo || pos >= er.hi) return;
+        const bool is_fw = fw < rv;
+        const uint64_t key = is_fw ? fw : rv;
+        if (filt.filt_lo != 0 || filt.filt_hi != filt.map_count) {
+            const uint32_t m = map_index(key, filt.map_count, filt.map_mask);
+            if (m < filt.filt_lo || m >= filt.filt_hi) return;
+        }
+        uint32_t ins = 0;
+        if (table_add(t, key, 1, edge_pack(is_fw, prev, next), nullptr, &ins)) ++n_kmers;
+        n_new += ins;
+    });
+    uint64_t a = block_sum(n_new), b = block_sum(n_kmers);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&t.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&t.st->kmers_added, (unsigned long long)b);
+    }
+}
+
+// K1 pass A: number of k-mers per tile (so that pass B can write in sequence order)
+__global__ __launch_bounds__(TILE_THREADS) void k_emit_count(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len,
+                                                              int k, unsigned long long* tile_counts) {
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        uint64_t total = block_sum(tile_lane_count(s_inv, k));
+        if (threadIdx.x == 0) tile_counts[tile] = total;
+    }
+}
+
+// exclusive scan of tile counts (single workgroup; n_tiles is len/4032, i.e. small)
+__global__ __launch_bounds__(1024) void k_exclusive_scan(unsigned long long* a, uint64_t n, unsigned long long* total) {
+    __shared__ unsigned long long s_part[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t lo = (uint64_t)tid * per, hi = lo + per < n ? lo + per : n;
+    unsigned long long sum = 0;
+    for (uint64_t i = lo; i < hi; ++i) sum += a[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; ++i) { unsigned long long v = s_part[i]; s_part[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long run = s_part[tid];
+    for (uint64_t i = lo; i < hi; ++i) { unsigned long long v = a[i]; a[i] = run; run += v; }
+}
+
+// K1 pass B: write (key, edge byte) records in sequence order at tile_offsets[tile] + rank in tile
+__global__ __launch_bounds__(TILE_THREADS) void k_emit_write(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+                                                              const unsigned long long* tile_offsets,
+                                                              uint64_t* keys, uint8_t* edges, uint64_t cap) {
+    __shared__ uint32_t s_wave[TILE_THREADS / 64];
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    const int tid = threadIdx.x;
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        const uint32_t mine = tile_lane_count(s_inv, k);
+        // exclusive prefix of `mine` over the workgroup: wave scan + wave totals
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t n = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += n; }
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) wave_base += s_wave[w];
+        uint64_t out = tile_offsets[tile] + wave_base + (incl - mine);
+        tile_lane_scan(s_codes, s_inv, lo_valid, tile, k, [&](uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+            const bool is_fw = fw < rv;
+            if (out < cap) {
+                keys[out] = is_fw ? fw : rv;
+                edges[out] = pack_to_edge_byte(edge_pack(is_fw, prev, next));
+            }
+            ++out;
+        });
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// partitioned count path (kq_partition.h)
+// ------------------------------------------------------------------------------------------------
+// No per-record and no per-run global atomics: every workgroup gets PRIVATE output cursors from a
+// counting pass (count matrix -> exclusive scan), because reservation atomics on a few hundred
+// shared cursors serialise per address (~11 ns each) and were the limiter of the first version.
+
+constexpr int P1_F = 4;                 // hist workgroups per scatter workgroup (hist is light on LDS)
+constexpr uint32_t P2_UNIT = 8 * MS_TILE;   // records per P2 work unit (never crosses a coarse bucket)
+
+// column of hist workgroup vb in the count matrix: the P1_F hist workgroups whose tiles one scatter
+// workgroup b owns (vb = b, b+G1, ...) are adjacent, so b's output range per bin is contiguous
+__device__ __forceinline__ uint32_t p1_col(uint32_t vb, uint32_t g1) { return (vb % g1) * P1_F + vb / g1; }
+
+// P1 pass A: per-workgroup counts of coarse buckets -> M1[bin][column] (u64, bin-major)
+// BINMODE 0: generic p1_bin (owner split / map-range filter); 1: coarse bucket of the table region; 2: top hash
+// bits (narrow).  The specialised modes keep the 16 unrolled steps free of wave-uniform branches.
+template <int BINMODE>
+__device__ __forceinline__ uint32_t p1_bin_of(const PartCfg& cfg, uint64_t key, uint64_t h) {
+    return BINMODE == 2 ? (uint32_t)(h >> (64 - NARROW_CBITS)) : BINMODE == 1 ? (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift) : p1_bin(cfg, key, h);
+}
+// KC != 0: k is the compile-time constant KC (the default k = 21 gets its own instantiation: every
+// k-dependent shift and mask of the 16 scan steps and of the hash folds to an immediate)
+template <int BINMODE, int KC>
+__global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k_arg,
+                                                          PartCfg cfg, EmitRange er, uint32_t g1, unsigned long long* __restrict__ m1) {
+    const int k = KC ? KC : k_arg;
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    __shared__ uint32_t s_hist[NB_MAX];
+    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += TILE_THREADS) s_hist[b] = 0;
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);         // barrier inside (also covers the zeroing above)
+        tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
+            if (valid) {
+                const uint64_t key = fw < rv ? fw : rv;
+                const uint32_t b = p1_bin_of<BINMODE>(cfg, key, table_hash(key, (uint32_t)k));
+                if (BINMODE != 0 || b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
+            }
+        });
+        __syncthreads();
+    }
+    __syncthreads();
+    const uint64_t cols = (uint64_t)g1 * P1_F;
+    const uint32_t col = p1_col(blockIdx.x, g1);
+    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += TILE_THREADS) m1[(uint64_t)b * cols + col] = s_hist[b];
+}
+// after the scan of M1: coarse_off[b] = first output position of bucket b; [n_coarse] = #records
+__global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const unsigned long long* __restrict__ total, PartCfg cfg,
+                             uint32_t g1, unsigned long long* __restrict__ coarse_off) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < cfg.n_coarse) coarse_off[b] = m1[(uint64_t)b * g1 * P1_F];
+    if (b == cfg.n_coarse) coarse_off[b] = *total;
+}
+// P1 pass B: (key, edge) records into their coarse bucket, private cursors from the scanned M1
+template <int FMT, int NBC, int BINMODE, int KC>
+__global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 : 2) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k_arg,
+                                                             PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
+                                                             uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8;
+    constexpr int MS_FMT = TOP8 ? FMT_PACK8 : FMT;                      // TOP8 records are single u64 words like packed ones
+    const int k = KC ? KC : k_arg;
+    __shared__ MsShared<NBC, MS_FMT> s;
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    const uint64_t cols = (uint64_t)gridDim.x * P1_F;
+    for (uint32_t b = threadIdx.x; b < cfg.n_coarse; b += MS_THREADS) s.gbase[b] = (uint32_t)m1[(uint64_t)b * cols + (uint64_t)blockIdx.x * P1_F];
+#ifdef KQ_MS_STAMPS
+    if (threadIdx.x == 0) s.stamp_on = 0;
+#endif
+    uint4 nxt = tile_fetch(ab, lo_valid, hi_valid, blockIdx.x);
+    landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w);         // see k_lv_scatter: keeps the loop header free of a store-draining wait
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_store(nxt, lo_valid, hi_valid, tile, s_codes, s_inv);        // barrier inside (covers the cursor init)
+        if (tile + gridDim.x < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + gridDim.x);   // in flight during the split
+        uint64_t rec[MS_ITEMS];
+        uint32_t aux[MS_ITEMS], bin[MS_ITEMS];
+        tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int i, bool valid, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+            const bool is_fw = fw < rv;
+            const uint64_t key = is_fw ? fw : rv;
+            const uint64_t h = table_hash(key, (uint32_t)k);             // the only hash of this k-mer on the whole path
+            if (WIDE) {
+                rec[i] = cfg.raw_out ? key : h;                             // raw keys only for kq_emit_partitioned_dev's caller
+                const uint32_t e = edge_idx6(is_fw, prev, next);
+                aux[i] = aux_fmt == AUX_IDX6 ? e : idx6_to_edge_byte(e);
+            } else if (TOP8) {
+                rec[i] = top8_rec(h, edge_idx6(is_fw, prev, next));
+                aux[i] = 0;
+            } else if (NARROW) {
+                rec[i] = narrow_word(narrow_main(h), narrow_aux(h, edge_idx6(is_fw, prev, next)), valid ? p1_bin_of<BINMODE>(cfg, key, h) : cfg.n_coarse);
+            } else {
+                rec[i] = rec_pack_hash(h, is_fw, prev, next);
+                aux[i] = 0;
+            }
+            if (!NARROW) bin[i] = valid ? p1_bin_of<BINMODE>(cfg, key, h) : cfg.n_coarse;
+        });
+        block_multisplit<MS_FMT>(s, rec, aux, bin, cfg.n_coarse, recs, recs_aux,
+                               [&] { landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w); });   // ends with a barrier
+    }
+}
+
+// ---- one generic level of the record split (LevelCfg) -----------------------------------------
+// work units: segment b is cut into ceil(size_b / P2_UNIT) units; unit_base = exclusive prefix
+__global__ __launch_bounds__(1024) void k_lv_units(const unsigned long long* __restrict__ seg_off, LevelCfg lv,
+                                                   unsigned long long* __restrict__ unit_base) {
+    __shared__ unsigned long long s_n[NB_MAX];
+    for (uint32_t b = threadIdx.x; b < lv.n_seg; b += blockDim.x)
+        s_n[b] = (seg_off[b + 1] - seg_off[b] + P2_UNIT - 1) / P2_UNIT;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (uint32_t b = 0; b < lv.n_seg; ++b) { unit_base[b] = run; run += s_n[b]; }
+        unit_base[lv.n_seg] = run;
+    }
+}
+__device__ __forceinline__ uint32_t seg_of_unit(const unsigned long long* unit_base, uint32_t n_seg, uint64_t u) {
+    uint32_t lo = 0, hi = n_seg;                  // largest b with unit_base[b] <= u (skips empty segments)
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (unit_base[mid] <= u) lo = mid; else hi = mid; }
+    return lo;
+}
+// pass A: per-unit bin counts -> M2[unit][bin] (u32)
+template <int FMT>
+__global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restrict__ recs, LevelCfg lv,
+                                                        const unsigned long long* __restrict__ seg_off,
+                                                        const unsigned long long* __restrict__ unit_base, uint32_t* __restrict__ m2) {
+    __shared__ uint32_t s_hist[NB_MAX];
+    const uint64_t n_units = unit_base[lv.n_seg];
+    for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint32_t b = seg_of_unit(unit_base, lv.n_seg, u);
+        const uint64_t lo = seg_off[b] + (u - unit_base[b]) * P2_UNIT;
+        const uint64_t hi = lo + P2_UNIT < seg_off[b + 1] ? lo + P2_UNIT : seg_off[b + 1];
+        for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) s_hist[i] = 0;
+        __syncthreads();
+        // 8 records per lane in flight, loaded unconditionally (index clamped): a load inside a branch per
+        // iteration costs a full memory latency per record (s_waitcnt vmcnt(0) right behind it)
+        const uint64_t last = hi - 1;                                   // a unit is never empty
+        if (FMT == FMT_NARROW) {
+            // 16-byte loads of four u32 records at absolute quad indices (the array is 16-byte aligned and has
+            // slack behind its last record); the quads at the unit's ends are masked per element
+            const uint4* v4 = reinterpret_cast<const uint4*>(recs);
+            const uint64_t q0 = lo >> 2, q1 = (hi + 3) >> 2;
+            for (uint64_t qb = q0; qb < q1; qb += 4ull * MS_THREADS) {
+                uint4 q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = v4[min(qb + (uint64_t)j * MS_THREADS + threadIdx.x, q1 - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t qi = qb + (uint64_t)j * MS_THREADS + threadIdx.x;
+                    const uint32_t e[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint64_t ri = 4 * qi + c;
+                        if (qi < q1 && ri >= lo && ri < hi) atomicAdd(&s_hist[narrow_bin(lv, b, e[c])], 1u);
+                    }
+                }
+            }
+        } else
+        for (uint64_t base = lo; base < hi; base += 8ull * MS_THREADS) {
+            uint64_t r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint64_t i = min(base + (uint64_t)j * MS_THREADS + threadIdx.x, last);
+                r[j] = FMT == FMT_NARROW ? (uint64_t)reinterpret_cast<const uint32_t*>(recs)[i] : recs[i];      // narrow: the u32 array alone decides the bin
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi) {
+                    const uint32_t bin = FMT == FMT_NARROW ? narrow_bin(lv, b, (uint32_t)r[j])
+                        : FMT == FMT_TOP8 ? narrow_bin(lv, b, (uint32_t)(r[j] >> 32))
+                        : (FMT == FMT_PACK8 && lv.top8) ? (uint32_t)(rec_hash<false>(r[j]) >> (64 - NARROW_CBITS))
+                        : level_bin(lv, b, hash_region(lv.in_raw ? table_hash(r[j], lv.k) : rec_hash<FMT == FMT_WIDE>(r[j]), lv.n_regions));
+                    atomicAdd(&s_hist[bin], 1u);
+                }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) m2[u * lv.nb + i] = s_hist[i];
+        __syncthreads();
+    }
+}
+// per output group (segment b, bin): exclusive prefix of its counts over the segment's units
+// (in place), group total out.  One WAVE per group: a segment can have thousands of units (the
+// flat -> coarse level has a single segment), so the prefix runs 64 units at a time.
+__global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, LevelCfg lv, const unsigned long long* __restrict__ unit_base,
+                                                    unsigned long long* __restrict__ group_count) {
+    const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (r >= (uint64_t)lv.n_seg * lv.nb) return;                     // wave-uniform
+    const uint32_t b = (uint32_t)(r / lv.nb), bin = (uint32_t)(r % lv.nb);
+    const uint64_t u0 = unit_base[b], u1 = unit_base[b + 1];
+    unsigned long long run = 0;
+    for (uint64_t base = u0; base < u1; base += 64) {
+        const uint64_t u = base + lane;
+        const uint32_t c = u < u1 ? m2[u * lv.nb + bin] : 0u;
+        unsigned long long incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long n = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += n; }
+        if (u < u1) m2[u * lv.nb + bin] = (uint32_t)(run + incl - c);   // a group holds < 2^32 records of one batch
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) group_count[r] = run;
+}
+// pass B: records -> grouped by (segment, bin); private cursors = group_base + unit prefix
+#ifndef KQ_LV_THREADS
+#define KQ_LV_THREADS 512
+#define KQ_LV_ITEMS 8
+#define KQ_LV_OCC 4
+#endif
+constexpr int LV_THREADS = KQ_LV_THREADS, LV_ITEMS = KQ_LV_ITEMS, LV_TILE = LV_THREADS * LV_ITEMS;       // records come from memory: more waves per LDS footprint
+template <int FMT, int NBC>
+__global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
+                                                           const unsigned long long* __restrict__ seg_off,
+                                                           const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
+                                                           const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out,
+                                                           uint8_t* __restrict__ out_aux) {
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, CONVERT = FMT == FMT_PACK8_TO_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
+    constexpr int MS_FMT = CONVERT ? FMT_NARROW : TOP8 ? FMT_PACK8 : FMT;                  // format of the records this kernel writes
+    const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
+    __shared__ MsShared<NBC, MS_FMT> s;
+    const uint32_t nb = lv.nb;
+    const uint64_t n_units = unit_base[lv.n_seg];
+    for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint32_t b = seg_of_unit(unit_base, lv.n_seg, u);
+        const uint64_t lo = seg_off[b] + (u - unit_base[b]) * P2_UNIT;
+        const uint64_t hi = lo + P2_UNIT < seg_off[b + 1] ? lo + P2_UNIT : seg_off[b + 1];
+        for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS) s.gbase[i] = (uint32_t)(group_base[(uint64_t)b * nb + i] + m2[u * nb + i]);
+#ifdef KQ_MS_STAMPS
+        if (threadIdx.x == 0) { s.stamp_on = 1; s.stamp_last = __builtin_amdgcn_s_memtime(); }
+#endif
+        __syncthreads();
+        // software pipeline: the next round's records are loaded before this round is split
+        // (loads are unconditional, index clamped to the unit: a branch around a load makes the compiler
+        // drain ALL outstanding loads -- the prefetch included -- at the first use)
+        uint64_t nxt[LV_ITEMS];
+        uint32_t nxt_aux[LV_ITEMS];
+        const uint64_t last = hi - 1;                                   // a unit is never empty
+#pragma unroll
+        for (int j = 0; j < LV_ITEMS; ++j) {
+            const uint64_t i = min(lo + (uint64_t)j * LV_THREADS + threadIdx.x, last);
+            nxt[j] = NARROW ? (uint64_t)recs32[i] : recs[i];
+            nxt_aux[j] = HAS_AUX ? recs_aux[i] : 0;
+        }
+        // wait for the first round's records HERE: otherwise the loop header inherits "loads pending" from
+        // this path and its s_waitcnt vmcnt(0) also drains the previous round's stores on the back edge
+#pragma unroll
+        for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (HAS_AUX) landed(nxt_aux[j]); }
+        for (uint64_t pos = lo; pos < hi; pos += LV_TILE) {
+            uint64_t rec[LV_ITEMS];
+            uint32_t aux[LV_ITEMS], bin[LV_ITEMS];
+#pragma unroll
+            for (int j = 0; j < LV_ITEMS; ++j) {
+                const uint64_t i = pos + (uint64_t)j * LV_THREADS + threadIdx.x;
+                rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.k) : nxt[j];      // raw keys become hashes at the first level
+                aux[j] = nxt_aux[j];
+                if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : narrow_bin(lv, b, (uint32_t)rec[j]));
+                else if (CONVERT) {
+                    const uint64_t hh = rec_hash<false>(rec[j]);
+                    rec[j] = narrow_word(narrow_main(hh), narrow_aux(hh, (uint32_t)(rec[j] >> REC_EDGE_SHIFT) & 63u), i >= hi ? nb : (uint32_t)(hh >> (64 - NARROW_CBITS)));
+                }
+                else if (TOP8) bin[j] = i >= hi ? nb : narrow_bin(lv, b, (uint32_t)(rec[j] >> 32));
+                else bin[j] = i >= hi ? nb : level_bin(lv, b, hash_region(rec_hash<WIDE>(rec[j]), lv.n_regions));
+            }
+#pragma unroll
+            for (int j = 0; j < LV_ITEMS; ++j) {
+                const uint64_t i = min(pos + LV_TILE + (uint64_t)j * LV_THREADS + threadIdx.x, last);
+                nxt[j] = NARROW ? (uint64_t)recs32[i] : recs[i];
+                nxt_aux[j] = HAS_AUX ? recs_aux[i] : 0;
+            }
+            block_multisplit<MS_FMT, LV_THREADS, LV_ITEMS>(s, rec, aux, bin, nb, out, out_aux, [&] {
+#pragma unroll
+                for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (HAS_AUX) landed(nxt_aux[j]); }
+            });
+        }
+    }
+}
+__global__ void k_set2(unsigned long long* p, unsigned long long a, unsigned long long b) { p[0] = a; p[1] = b; }
+
+// multi-block exclusive scan helpers (chunks of SCAN_CHUNK elements per workgroup)
+constexpr uint32_t SCAN_CHUNK = 16384;
+__global__ __launch_bounds__(1024) void k_scan_sums(const unsigned long long* __restrict__ a, uint64_t n, unsigned long long* __restrict__ sums) {
+    const uint64_t lo = (uint64_t)blockIdx.x * SCAN_CHUNK, hi = lo + SCAN_CHUNK < n ? lo + SCAN_CHUNK : n;
+    unsigned long long v = 0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 1024) v += a[i];
+    uint64_t t = block_sum(v);
+    if (threadIdx.x == 0) sums[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(unsigned long long* __restrict__ a, uint64_t n, const unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long s_part[1024];
+    const uint64_t lo = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * (SCAN_CHUNK / 1024);
+    unsigned long long v[SCAN_CHUNK / 1024], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_CHUNK / 1024; ++j) { v[j] = lo + j < n ? a[lo + j] : 0; sum += v[j]; }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x < 64) {                      // wave 0 scans the 1024 partials, 16 per lane
+        unsigned long long loc[16], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { loc[j] = s_part[threadIdx.x * 16 + j]; tot += loc[j]; }
+        unsigned long long incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { unsigned long long nn = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += nn; }
+        unsigned long long run = incl - tot;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s_part[threadIdx.x * 16 + j] = run; run += loc[j]; }
+    }
+    __syncthreads();
+    unsigned long long run = sums[blockIdx.x] + s_part[threadIdx.x];
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_CHUNK / 1024; ++j) { if (lo + j < n) a[lo + j] = run; run += v[j]; }
+}
+
+
+// P3: one workgroup per table region.  The region's slots (REGION_SLOTS x 24 B) are staged in LDS, all
+// records of the region are applied with LDS atomics (same two-tier rule as table_add), and the
+// image is streamed back.  Global atomics only for the rare high-copy tier and the two totals.
+#ifdef KQ_STAMPS   // diagnostic build only (never shipped): per-phase cycle sums of k_count_regions
+__device__ unsigned long long g_stamps[8];
+#define KQ_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                         __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) atomicAdd(&g_stamps[i], t_ - stamp_last); stamp_last = t_; } while (0)
+#endif
+#ifdef KQ_MS_STAMPS
+extern "C" int kq_debug_ms_stamps(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(kq::g_ms_stamps), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kq::g_ms_stamps), 128);
+}
+#endif
+#ifdef KQ_STAMPS
+extern "C" int kq_debug_stamps(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 64);
+}
+#else
+#define KQ_STAMP(i) do { } while (0)
+#endif
+#ifndef KQ_P3_THREADS
+#define KQ_P3_THREADS 512
+#define KQ_P3_OCC 6
+#define KQ_P3_PF 2
+#endif
+constexpr int P3_THREADS = KQ_P3_THREADS;        // three 48 KiB images per CU (24 waves): with records double-buffered and groups handed out by ticket, one more region in flight per CU beats 2 x 1024 threads (whole count job 2.64 vs 2.67 ms)
+// Two instantiations share the regions: HOT = false takes the ordinary ones (deep record prefetch, no
+// folding state: fits the 80 VGPRs that let three workgroups share a CU) and appends the skewed ones
+// to hot_list; HOT = true then walks that list with the folding loop.
+template <int FMT, bool HOT>
+__global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
+                                                              int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty,
+                                                              unsigned long long* __restrict__ hot_list /*[0] = count, then region ids*/,
+                                                              uint32_t narrow_rps /*FMT_NARROW: regions per top-bit bucket*/) {
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
+    const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
+    __shared__ uint64_t s_img[REGION_SLOTS * 3];
+    __shared__ unsigned long long s_new, s_kmers;
+    __shared__ unsigned int s_grp;
+    // high-copy tier of this region, aggregated in LDS: a repeat k-mer with millions of instances
+    // would otherwise serialise millions of global atomics on one side-table entry
+    constexpr int HC_LDS = 64;
+    __shared__ uint64_t s_hckey[HC_LDS];
+    __shared__ uint32_t s_hccnt[HC_LDS][8];
+    const int tid = threadIdx.x;
+    const uint64_t n_work = HOT ? hot_list[0] : t.n_regions;
+#ifdef KQ_STAMPS
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const uint64_t r = HOT ? hot_list[1 + w] : w;
+        const uint64_t lo = region_base[r], hi = region_base[r + 1];
+        const uint32_t narrow_bucket = (NARROW || TOP8) ? (uint32_t)r / narrow_rps : 0u;
+        if (lo == hi) {                                                 // block-uniform
+            if (!HOT && table_is_empty == 2) {    // lazy kq_clear: this launch initialises every region, also the ones without records
+                ulonglong2* g2 = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
+                for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) {
+                    const int w = 2 * i;
+                    g2[i] = make_ulonglong2(w % 3 == 0 ? EMPTY_KEY : 0ull, (w + 1) % 3 == 0 ? EMPTY_KEY : 0ull);
+                }
+            }
+            continue;
+        }
+        // folding costs a ballot + shuffle per iteration: only regions that receive far more records than
+        // they have slots (skew, or very deep coverage) take that path, in the second launch
+        if (!HOT && hi - lo > 32ull * REGION_SLOTS) {
+            if (tid == 0) hot_list[1 + atomicAdd(&hot_list[0], 1ull)] = r;
+            continue;
+        }
+        if (tid < HC_LDS) {
+            s_hckey[tid] = EMPTY_KEY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_hccnt[tid][e] = 0;
+        }
+        uint4* gimg = reinterpret_cast<uint4*>(t.slots + (r << REGION_SHIFT));
+        uint4* limg = reinterpret_cast<uint4*>(s_img);
+        if (table_is_empty) {            // first batch after kq_create / kq_clear: the image is known, skip the 48 KiB read
+            for (int i = tid; i < (int)(REGION_SLOTS * 3); i += P3_THREADS) s_img[i] = (i % 3 == 0) ? EMPTY_KEY : 0ull;
+        } else {
+            for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+        }
+        if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = P3_THREADS / 64; }
+        __syncthreads();
+        KQ_STAMP(0);                                                    // region_base load + image init/load + barrier
+        uint32_t n_new = 0, n_ok = 0;
+        // Slot of `key` in the LDS image (word index), claiming an empty one if needed; REGION_SLOTS*3 = not found.
+        // The image is read with workgroup-scope relaxed atomic loads on the __shared__ array itself: a
+        // volatile access through a generic pointer compiles to flat_load + s_waitcnt vmcnt(0), which also
+        // drains the record prefetches on every probe.
+        // Four slots of the probe sequence are read per LDS round trip: a wave needs the MAXIMUM probe count of
+        // its 64 lanes in dependent round trips (4-6 at load 0.5 when probing one slot at a time -- the walk
+        // was bound by exactly that latency chain), now a quarter of it.  The snapshot is scanned in order; an
+        // EMPTY slot is claimed with a CAS whose result decides (slots only ever go EMPTY -> key).
+        auto find_slot = [&](uint64_t key, uint64_t h) -> uint32_t {
+            const uint32_t off = hash_offset(h, t.k);
+            for (uint32_t base = 0; base < REGION_SLOTS; base += 4) {
+                uint32_t w[4];
+                uint64_t c[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w[j] = 3u * ((off + base + j) & (REGION_SLOTS - 1));
+                    c[j] = __hip_atomic_load(&s_img[w[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t cur = c[j];
+                    if (cur == EMPTY_KEY) {
+                        cur = atomicCAS((unsigned long long*)&s_img[w[j]], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                        if (cur == EMPTY_KEY) { ++n_new; return w[j]; }
+                    }
+                    if (cur == key) return w[j];
+                }
+            }
+            atomicOr(&t.st->err_table_full, 1u);
+            return REGION_SLOTS * 3;
+        };
+        // edge counts that no longer fit the u8 lanes: the region's LDS high-copy aggregation, global beyond 64 k-mers
+        auto add_wide = [&](uint64_t key, uint64_t h, const uint32_t (&e)[8]) {
+            int hslot = -1;
+            uint32_t hp = (uint32_t)(h >> 40) & (HC_LDS - 1);
+            for (int probe = 0; probe < HC_LDS; ++probe, hp = (hp + 1) & (HC_LDS - 1)) {
+                uint64_t cur = __hip_atomic_load(&s_hckey[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == EMPTY_KEY) cur = atomicCAS((unsigned long long*)&s_hckey[hp], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                if (cur == EMPTY_KEY || cur == key) { hslot = (int)hp; break; }
+            }
+            if (hslot >= 0) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd(&s_hccnt[hslot][w], e[w]);
+            } else {
+                HcSlot* hs = hc_upsert(t, key);
+                if (!hs) { atomicOr(&t.st->err_hc_full, 1u); return; }
+#pragma unroll
+                for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd((unsigned long long*)&hs->cnt[w], (unsigned long long)e[w]);
+            }
+        };
+        // one record: `pack` holds its (at most two) edge bits, one per byte lane
+        auto apply1 = [&](uint64_t key, uint64_t h, uint64_t pack) {
+            const uint32_t w = find_slot(key, h);
+            if (w == REGION_SLOTS * 3) return;
+            ++n_ok;
+            const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], 1ull);
+            if (!pack) return;
+            if (old < LOW_TIER_MAX) { atomicAdd((unsigned long long*)&s_img[w + 1], (unsigned long long)pack); return; }
+            uint32_t e1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e1[q] = (uint32_t)(pack >> (8 * q)) & 1u;
+            add_wide(key, h, e1);
+        };
+        // `cnt` folded instances of `key` with edge counts e[0..7] (each <= cnt)
+        auto apply = [&](uint64_t key, const uint32_t (&e)[8], uint32_t cnt) {
+            const uint64_t h = table_hash(key, t.k);
+            const uint32_t w = find_slot(key, h);
+            if (w == REGION_SLOTS * 3) return;
+            n_ok += cnt;
+            const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], (unsigned long long)cnt);
+            uint32_t any = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) any |= e[q];
+            if (!any) return;
+            if (old + cnt <= LOW_TIER_MAX) {                        // every e[q] <= cnt <= 254: fits the u8 lanes
+                uint64_t pack = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pack |= (uint64_t)e[q] << (8 * q);
+                atomicAdd((unsigned long long*)&s_img[w + 1], (unsigned long long)pack);
+                return;
+            }
+            add_wide(key, h, e);
+        };
+        // Hot k-mers (repeats, homopolymers) put most lanes of a wave on ONE slot, batch after batch.
+        // Lanes that share the first active lane's key are folded into a per-wave accumulator kept in
+        // registers (wave-uniform); it is flushed to LDS only when the hot key changes.
+        auto run = [&](auto fold_tag) {
+        constexpr bool FOLD = decltype(fold_tag)::value;
+        bool have_acc = false;
+        uint64_t acc_key = 0;
+        uint32_t acc_cnt = 0, acc_e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // Records are double-buffered in registers: the loads of the NEXT group of PF records per lane are
+        // issued (unconditionally, index clamped: no branch around them) before the current group is
+        // walked, so the only wait sits at the top of an iteration on loads that had a whole group's walk
+        // to land.  (A conditional load per record made the compiler wait vmcnt(0) right after issuing
+        // the next prefetch: a full HBM latency per record, ~4k cycles.)
+        constexpr int PF = KQ_P3_PF;
+        uint64_t nxt_rec[PF];
+        uint32_t nxt_aux[PF];
+        const uint64_t last = hi - 1;                                  // hi > lo here
+        // groups of PF*64 records are handed to waves from an LDS ticket: waves that hit long probe
+        // chains or contended slots take fewer groups, so all waves reach the barrier together
+        constexpr uint64_t GRP = 64ull * PF;
+        const uint32_t lane = tid & 63;
+        uint32_t g_cur = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const uint64_t j = min(lo + g_cur * GRP + (uint64_t)q * 64 + lane, last);
+            nxt_rec[q] = NARROW ? (uint64_t)recs32[j] : recs[j];
+            nxt_aux[q] = HAS_AUX ? recs_aux[j] : 0u;
+        }
+        while (lo + g_cur * GRP < hi) {                                 // wave-uniform
+          uint64_t cur_rec[PF];
+          uint32_t cur_aux[PF];
+#pragma unroll
+          for (int q = 0; q < PF; ++q) { cur_rec[q] = nxt_rec[q]; cur_aux[q] = nxt_aux[q]; }
+          uint32_t g_nxt = 0;
+          if (lane == 0) g_nxt = atomicAdd(&s_grp, 1u);
+          g_nxt = __builtin_amdgcn_readfirstlane(g_nxt);
+#pragma unroll
+          for (int q = 0; q < PF; ++q) {
+            const uint64_t j = min(lo + g_nxt * GRP + (uint64_t)q * 64 + lane, last);
+            nxt_rec[q] = NARROW ? (uint64_t)recs32[j] : recs[j];
+            nxt_aux[q] = HAS_AUX ? recs_aux[j] : 0u;
+          }
+          const uint64_t base = lo + g_cur * GRP;
+          g_cur = g_nxt;
+#pragma unroll
+          for (int q = 0; q < PF; ++q) {
+            const uint64_t i = base + (uint64_t)q * 64 + lane;
+            bool active = i < hi;
+            const uint64_t rec = cur_rec[q];
+            const uint32_t aux = cur_aux[q];
+            uint64_t key = 0, pack = 0;
+            const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec, aux) : TOP8 ? top8_hash(narrow_bucket, rec) : rec_hash<WIDE>(rec);
+            if (active) {
+                key = key_of_hash(h, t.k);                                   // the mix is a bijection: no key in the record
+                pack = NARROW ? idx6_to_pack(aux >> 2) : TOP8 ? idx6_to_pack((uint32_t)rec & 63u)
+                     : WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
+            }
+            const uint64_t act = FOLD ? __ballot(active) : 0ull;
+            if (FOLD && act) {
+                const int lead = __ffsll((unsigned long long)act) - 1;
+                const uint64_t lead_key = __shfl(key, lead, 64);
+                const bool in_grp = active && key == lead_key;
+                const uint64_t grp = __ballot(in_grp);
+                if (__popcll(grp) >= 8) {
+                    uint64_t sum = in_grp ? pack : 0ull;            // byte lanes <= 64: no carries
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                    if (have_acc && acc_key != lead_key) {
+                        if ((tid & 63) == 0) apply(acc_key, acc_e, acc_cnt);
+                        have_acc = false;
+                    }
+                    if (!have_acc) {
+                        have_acc = true; acc_key = lead_key; acc_cnt = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) acc_e[w] = 0;
+                    }
+                    acc_cnt += (uint32_t)__popcll(grp);
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) acc_e[w] += (uint32_t)(sum >> (8 * w)) & 0xFFu;
+                    if (in_grp) active = false;
+                }
+            }
+            if (active) apply1(key, h, pack);
+          }
+        }
+        if (have_acc && (tid & 63) == 0) apply(acc_key, acc_e, acc_cnt);
+        };
+        run(std::integral_constant<bool, HOT>{});
+        KQ_STAMP(1);                                                    // record walk
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { n_new += __shfl_down(n_new, o, 64); n_ok += __shfl_down(n_ok, o, 64); }
+        if ((tid & 63) == 0) { if (n_new) atomicAdd(&s_new, (unsigned long long)n_new); if (n_ok) atomicAdd(&s_kmers, (unsigned long long)n_ok); }
+        __syncthreads();
+        if (tid < HC_LDS && s_hckey[tid] != EMPTY_KEY) {            // flush the region's high-copy sums: one entry per k-mer
+            HcSlot* hs = hc_upsert(t, s_hckey[tid]);
+            if (!hs) atomicOr(&t.st->err_hc_full, 1u);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (s_hccnt[tid][e]) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)s_hccnt[tid][e]);
+            }
+        }
+        KQ_STAMP(2);                                                    // barrier (slowest wave) + high-copy flush
+        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) gimg[i] = limg[i];
+        KQ_STAMP(3);                                                    // image store issue
+        if (tid == 0) {
+            if (s_new) atomicAdd(&t.st->slots_used, s_new);
+            if (s_kmers) atomicAdd(&t.st->kmers_added, s_kmers);
+        }
+        __syncthreads();
+        KQ_STAMP(4);                                                    // final barrier
+    }
+}
+
+
+// K3 on partitioned records (counters only): the assembly's k-mers go through the same P1 / level split as
+// reads, then one workgroup per table region stages the region image in LDS (read-only) and evaluates its
+// records there -- sequential HBM traffic instead of one random 64-byte sector per k-mer.  A record holds
+// everything evaluateSegment needs (src/kreeq.cpp:145-216): the hash (-> key) and the indices of the
+// fw / bw edge the assembly continues with (edge_idx6: the strand mapping of :178-210 is already applied).
+template <int FMT>
+__global__ __launch_bounds__(P3_THREADS, 6) void k_lookup_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
+                                                                   const unsigned long long* __restrict__ region_base, uint32_t narrow_rps,
+                                                                   uint32_t cov_cutoff, unsigned long long* __restrict__ counters) {
+    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
+    const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
+    __shared__ uint64_t s_img[REGION_SLOTS * 3];
+    const int tid = threadIdx.x;
+    uint32_t missing = 0, total = 0, edge_missing = 0;
+    for (uint64_t r = blockIdx.x; r < t.n_regions; r += gridDim.x) {
+        const uint64_t lo = region_base[r], hi = region_base[r + 1];
+        if (lo == hi) continue;                                         // block-uniform
+        const uint4* gimg = reinterpret_cast<const uint4*>(t.slots + (r << REGION_SHIFT));
+        uint4* limg = reinterpret_cast<uint4*>(s_img);
+        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+        __syncthreads();
+        const uint32_t narrow_bucket = (NARROW || TOP8) ? (uint32_t)r / narrow_rps : 0u;
+        const uint64_t last = hi - 1;
+        for (uint64_t base = lo; base < hi; base += 2ull * P3_THREADS) {
+            uint64_t rec[2];
+            uint32_t aux[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint64_t j = min(base + (uint64_t)q * P3_THREADS + tid, last);
+                rec[q] = NARROW ? (uint64_t)recs32[j] : recs[j];
+                aux[q] = HAS_AUX ? recs_aux[j] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (base + (uint64_t)q * P3_THREADS + tid >= hi) continue;
+                const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec[q], aux[q]) : TOP8 ? top8_hash(narrow_bucket, rec[q]) : rec_hash<WIDE>(rec[q]);
+                const uint64_t key = key_of_hash(h, t.k);
+                const uint32_t idx6 = NARROW ? aux[q] >> 2 : TOP8 ? (uint32_t)rec[q] & 63u : WIDE ? aux[q] : (uint32_t)(rec[q] >> REC_EDGE_SHIFT) & 63u;
+                const uint32_t off = hash_offset(h, t.k);
+                uint32_t found = REGION_SLOTS * 3;
+                for (uint32_t pb = 0; pb < REGION_SLOTS && found == REGION_SLOTS * 3; pb += 4) {     // :153, four slots per LDS round trip
+                    uint32_t w[4];
+                    uint64_t c[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { w[j] = 3u * ((off + pb + j) & (REGION_SLOTS - 1)); c[j] = s_img[w[j]]; }
+                    bool stop = false;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!stop && c[j] == key) { found = w[j]; stop = true; }
+                        if (!stop && c[j] == EMPTY_KEY) stop = true;
+                    }
+                    if (stop) break;
+                }
+                uint64_t cov = 0, e8 = 0;
+                const HcSlot* hs = nullptr;
+                if (found != REGION_SLOTS * 3) {
+                    e8 = s_img[found + 1]; cov = s_img[found + 2];
+                    if (cov > LOW_TIER_MAX) hs = hc_find(t, key);                                    // :156-166 (32-bit tier)
+                }
+                if (cov == 0 || cov < cov_cutoff) ++missing;                                         // :172-175
+                else {
+                    const uint32_t f = idx6 & 7u, b = (idx6 >> 3) & 7u;
+                    auto absent = [&](uint32_t e) { return ((e8 >> (8 * e)) & 0xFF) == 0 && !(hs && hs->cnt[e]); };
+                    if (f < 4 && b < 4 && absent(f) && absent(4 + b)) ++edge_missing;                 // :176-215
+                }
+                ++total;                                                                              // :216
+            }
+        }
+        __syncthreads();                                                // the next region overwrites the image
+    }
+    const uint64_t a = block_sum(missing), b = block_sum(total), c = block_sum(edge_missing);
+    if (threadIdx.x == 0) {                                                                           // :223-225
+        if (a) atomicAdd(&counters[0], (unsigned long long)a);
+        if (b) atomicAdd(&counters[1], (unsigned long long)b);
+        if (c) atomicAdd(&counters[2], (unsigned long long)c);
+    }
+}
+
+// K2 on explicit records: processBuffers :160-206
+__global__ __launch_bounds__(256) void k_insert_records(TableView t, const uint64_t* __restrict__ keys,
+                                                         const uint8_t* __restrict__ edges, uint64_t n) {
+    uint32_t n_new = 0;
+    uint64_t n_ok = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t ins = 0;
+        if (table_add(t, keys[i], 1, edge_byte_to_pack(edges[i]), nullptr, &ins)) ++n_ok;
+        n_new += ins;
+    }
+    uint64_t a = block_sum(n_new), b = block_sum(n_ok);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&t.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&t.st->kmers_added, (unsigned long long)b);
+    }
+}
+
+// import / union: add logical entries (kunion + mergeSubMaps, src/graph-builder.cpp:297-432)
+__device__ __forceinline__ void add_logical(const TableView& t, uint64_t key, const uint32_t* e, uint32_t cov,
+                                            uint32_t& n_new, uint64_t& n_cov) {
+    uint64_t pack = 0;
+    bool fits = cov <= LOW_TIER_MAX;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { if (e[i] > LOW_TIER_MAX) fits = false; pack |= (uint64_t)(e[i] & 0xFF) << (8 * i); }
+    uint32_t ins = 0;
+    // when the entry itself is beyond the low tier, table_add routes all of it to the wide counters
+    if (table_add(t, key, cov, fits ? pack : 0, fits ? nullptr : e, &ins)) n_cov += cov;
+    n_new += ins;
+}
+__global__ __launch_bounds__(256) void k_import(TableView t, const kq_entry* __restrict__ in, uint64_t n) {
+    uint32_t n_new = 0;
+    uint64_t n_cov = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t e[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { e[w] = in[i].fw[w]; e[4 + w] = in[i].bw[w]; }
+        add_logical(t, in[i].key, e, in[i].cov, n_new, n_cov);
+    }
+    uint64_t a = block_sum(n_new), b = block_sum(n_cov);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&t.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&t.st->kmers_added, (unsigned long long)b);
+    }
+}
+// K4: dst += src (both on this device)
+__global__ __launch_bounds__(256) void k_merge(TableView dst, TableView src) {
+    uint32_t n_new = 0;
+    uint64_t n_cov = 0;
+    const uint64_t n = src.n_regions << REGION_SHIFT;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Slot* s = src.slots + i;
+        if (s->key == EMPTY_KEY) continue;
+        Logical L = slot_logical(src, s);
+        add_logical(dst, s->key, L.e, L.cov, n_new, n_cov);
+    }
+    uint64_t a = block_sum(n_new), b = block_sum(n_cov);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&dst.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&dst.st->kmers_added, (unsigned long long)b);
+    }
+}
+// K4 by regions: dst += src without a global atomic per entry.  Both tables place a key by the same hash, so
+// the entries of dst region r can only come from the one or two (in general: a contiguous range of) src
+// regions that cover the same hash interval.  One workgroup per dst region: its image is staged in LDS
+// (or created there when dst is empty), the covering src regions are streamed, their entries that hash to r
+// are added with the rule of add_logical / table_add, and the image is written back.
+__global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, TableView src, int dst_is_empty) {
+    __shared__ uint64_t s_img[REGION_SLOTS * 3];
+    const int tid = threadIdx.x;
+    uint32_t n_new = 0;
+    uint64_t n_cov = 0;
+    for (uint64_t r = blockIdx.x; r < dst.n_regions; r += gridDim.x) {
+        uint4* gimg = reinterpret_cast<uint4*>(dst.slots + (r << REGION_SHIFT));
+        uint4* limg = reinterpret_cast<uint4*>(s_img);
+        if (dst_is_empty) {
+            for (int i = tid; i < (int)(REGION_SLOTS * 3); i += P3_THREADS) s_img[i] = (i % 3 == 0) ? EMPTY_KEY : 0ull;
+        } else {
+            for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+        }
+        __syncthreads();
+        // hash interval of dst region r (top 32 bits): [ceil(r 2^32 / R), ceil((r+1) 2^32 / R) - 1]
+        const uint64_t R = dst.n_regions;
+        const uint32_t h_lo = (uint32_t)(((r << 32) + R - 1) / R), h_hi = (uint32_t)((((r + 1) << 32) + R - 1) / R - 1);
+        const uint64_t s_lo = __umulhi(h_lo, (uint32_t)src.n_regions), s_hi = __umulhi(h_hi, (uint32_t)src.n_regions);
+        for (uint64_t sr = s_lo; sr <= s_hi; ++sr) {
+            const Slot* sslots = src.slots + (sr << REGION_SHIFT);
+            // the whole source region in flight at once (three 8-byte loads per slot, unconditional): a load behind
+            // the key test would cost two dependent memory round trips per slot
+            constexpr int SPT = REGION_SLOTS / P3_THREADS;
+            uint64_t sk[SPT], se[SPT], sc[SPT];
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) { const Slot* sp = sslots + tid + j * P3_THREADS; sk[j] = sp->key; se[j] = sp->edges8; sc[j] = sp->cov; }
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const uint64_t key = sk[j];
+                if (key == EMPTY_KEY) continue;
+                const uint64_t h = table_hash(key, dst.k);
+                if (hash_region(h, R) != r) continue;
+                const Logical L = logical_of(src, key, se[j], sc[j]);
+                uint64_t pack = 0;
+                bool fits = L.cov <= LOW_TIER_MAX, any = false;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { if (L.e[e] > LOW_TIER_MAX) fits = false; any |= L.e[e] != 0; pack |= (uint64_t)(L.e[e] & 0xFF) << (8 * e); }
+                // find-or-claim in the LDS image, four slots per round trip
+                const uint32_t off = hash_offset(h, dst.k);
+                uint32_t w = REGION_SLOTS * 3;
+                for (uint32_t pb = 0; pb < REGION_SLOTS && w == REGION_SLOTS * 3; pb += 4) {
+                    uint32_t ws[4];
+                    uint64_t c[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ws[j] = 3u * ((off + pb + j) & (REGION_SLOTS - 1)); c[j] = __hip_atomic_load(&s_img[ws[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (w != REGION_SLOTS * 3) break;
+                        uint64_t cur = c[j];
+                        if (cur == EMPTY_KEY) {
+                            cur = atomicCAS((unsigned long long*)&s_img[ws[j]], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                            if (cur == EMPTY_KEY) { ++n_new; w = ws[j]; break; }
+                        }
+                        if (cur == key) w = ws[j];
+                    }
+                }
+                if (w == REGION_SLOTS * 3) { atomicOr(&dst.st->err_table_full, 1u); continue; }
+                n_cov += L.cov;
+                const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], (unsigned long long)L.cov);
+                if (fits && old + L.cov <= LOW_TIER_MAX) {
+                    if (pack) atomicAdd((unsigned long long*)&s_img[w + 1], (unsigned long long)pack);
+                } else if (any) {                                       // beyond the u8 lanes: the wide counters (rare)
+                    HcSlot* hs = hc_upsert(dst, key);
+                    if (!hs) { atomicOr(&dst.st->err_hc_full, 1u); continue; }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (L.e[e]) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)L.e[e]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) gimg[i] = limg[i];
+        __syncthreads();
+    }
+    const uint64_t a = block_sum(n_new), b = block_sum(n_cov);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&dst.st->slots_used, (unsigned long long)a);
+        if (b) atomicAdd(&dst.st->kmers_added, (unsigned long long)b);
+    }
+}
+// rehash into a bigger table (growth): exact move of physical state
+__global__ __launch_bounds__(256) void k_rehash(TableView dst, const Slot* __restrict__ old, uint64_t n_old) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Slot s = old[i];
+        if (s.key == EMPTY_KEY) continue;
+        uint32_t ins = 0;
+        Slot* d = table_upsert(dst, s.key, &ins);
+        if (!d) { atomicOr(&dst.st->err_table_full, 1u); continue; }
+        d->edges8 = s.edges8;     // unique key per thread: plain stores
+        d->cov = s.cov;
+    }
+}
+__global__ __launch_bounds__(256) void k_rehash_hc(TableView dst, const HcSlot* __restrict__ old, uint64_t n_old) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (old[i].key == EMPTY_KEY) continue;
+        HcSlot* d = hc_upsert(dst, old[i].key);
+        if (!d) { atomicOr(&dst.st->err_hc_full, 1u); continue; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d->cnt[e] = old[i].cnt[e];
+    }
+}
+// table initialisation in one streaming pass: word i of the table is EMPTY_KEY when it is the key
+// word of a slot (i % words_per_slot == 0) and 0 otherwise; 16 B per lane per store.
+__global__ __launch_bounds__(256) void k_clear_slots(ulonglong2* p, uint32_t words_per_slot, uint64_t n_pairs) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w = 2 * i;
+        ulonglong2 v;
+        v.x = (w % words_per_slot == 0) ? EMPTY_KEY : 0ull;
+        v.y = ((w + 1) % words_per_slot == 0) ? EMPTY_KEY : 0ull;
+        p[i] = v;
+    }
+}
+
+// K5: summary (src/graph-builder.cpp:240-282).  hist_small[c] for cov < HIST_SMALL; rarer larger
+// coverages are appended to (big_cov, n_big) and folded on the host.
+constexpr uint32_t HIST_SMALL = 4096;
+struct SummaryOut {
+    unsigned long long total, uniq, distinct, edges, n_big, big_cap;
+};
+__global__ __launch_bounds__(256) void k_summary(TableView t, SummaryOut* out, unsigned long long* hist_small,
+                                                  uint32_t* big_cov) {
+    __shared__ uint32_t s_hist[HIST_SMALL];
+    for (uint32_t i = threadIdx.x; i < HIST_SMALL; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    uint64_t total = 0, uniq = 0, distinct = 0, edges = 0;
+    const uint64_t n = t.n_regions << REGION_SHIFT;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Slot* s = t.slots + i;
+        if (s->key == EMPTY_KEY) continue;
+        Logical L = slot_logical(t, s);
+        if (L.cov == 0) continue;                 // cannot happen (a key is inserted with cov >= 1)
+        uniq += (L.cov == 1);                     // :250
+#pragma unroll
+        for (int w = 0; w < 4; ++w)               // :254 / :263 -> fw>0 ? 1 : (bw>0 ? 1 : 0)
+            edges += (L.e[w] > 0) ? 1 : ((L.e[4 + w] > 0) ? 1 : 0);
+        ++distinct;
+        total += L.cov;                           // :274-278 (tot += cov * count)
+        if (L.cov < HIST_SMALL) atomicAdd(&s_hist[L.cov], 1u);
+        else {
+            unsigned long long o = atomicAdd(&out->n_big, 1ull);
+            if (o < out->big_cap) big_cov[o] = L.cov;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HIST_SMALL; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&hist_small[i], (unsigned long long)s_hist[i]);
+    uint64_t a = block_sum(total), b = block_sum(uniq), c = block_sum(distinct), d = block_sum(edges);
+    if (threadIdx.x == 0) {
+        if (a) atomicAdd(&out->total, (unsigned long long)a);
+        if (b) atomicAdd(&out->uniq, (unsigned long long)b);
+        if (c) atomicAdd(&out->distinct, (unsigned long long)c);
+        if (d) atomicAdd(&out->edges, (unsigned long long)d);
+    }
+}
+
+// export: logical entries of maps [lo, hi)
+__global__ __launch_bounds__(256) void k_export(TableView t, uint32_t map_count, uint32_t lo, uint32_t hi,
+                                                 kq_entry* out, uint64_t cap, unsigned long long* n_out) {
+    const uint64_t n = t.n_regions << REGION_SHIFT;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const Slot* s = t.slots + i;
+        const uint64_t key = s->key;
+        if (key == EMPTY_KEY) continue;
+        const uint32_t m = (uint32_t)(key % map_count);
+        if (m < lo || m >= hi) continue;
+        unsigned long long o = atomicAdd(n_out, 1ull);
+        if (out && o < cap) {
+            Logical L = slot_logical(t, s);
+            kq_entry e;
+            e.key = key;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { e.fw[w] = L.e[w]; e.bw[w] = L.e[4 + w]; }
+            e.cov = L.cov;
+            e.hc = L.cov > LOW_TIER_MAX;          // in maps32 iff total cov >= 255
+            out[o] = e;
+        }
+    }
+}
+
+// K3: evaluateSegment (src/kreeq.cpp:143-219) over a whole sequence (segments = ACGT runs).
+// One random 24-B probe per k-mer: measured at 27.7 G lookups/s this is the part's random 64-B
+// sector rate (a variant with 16 probes in flight per lane was not faster), so the kernel keeps the
+// simple one-k-mer-at-a-time form at full occupancy.  Per-base results are staged in LDS and
+// written out coalesced, and never read: a position is evaluated in exactly one map-range pass and
+// the caller zero-initialises the array (generateValidationVector, src/input.cpp:38-45), so only
+// found k-mers need a store.
+template <bool PER_BASE>
+__global__ __launch_bounds__(TILE_THREADS) void k_lookup(TableView t, const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len,
+                                                          int k, uint32_t map_count, uint32_t map_mask, uint32_t map_lo, uint32_t map_hi,
+                                                          uint32_t cov_cutoff, kq_dbgbase* __restrict__ per_base,
+                                                          unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t s_codes[TILE_THREADS];
+    __shared__ uint32_t s_inv[TILE_THREADS];
+    __shared__ kq_dbgbase s_pb[PER_BASE ? TILE_STARTS : 1];
+    const int tid = threadIdx.x;
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len);
+    uint32_t missing = 0, total = 0, edge_missing = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        if (PER_BASE) {
+            kq_dbgbase z; z.fw = z.bw = z.cov = 0; z.isFw = 0; z.pad[0] = z.pad[1] = z.pad[2] = 0;
+            for (int j = tid; j < TILE_STARTS; j += TILE_THREADS) s_pb[j] = z;
+            __syncthreads();
+        }
+        lane_scan_core<false>(s_codes, s_inv, lo_valid, tile, k,
+                              [&](int i, bool, uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+            const bool is_fw = fw < rv;                                    // :145
+            const uint64_t key = is_fw ? fw : rv;
+            const uint32_t m = map_mask ? (uint32_t)key & map_mask : (uint32_t)(key % map_count);   // :146
+            if (m < map_lo || m >= map_hi) return;                         // :150
+            kq_dbgbase b;
+            b.fw = b.bw = b.cov = 0; b.isFw = 0; b.pad[0] = b.pad[1] = b.pad[2] = 0;
+            Logical L;
+            const Slot* s = table_find(t, key);                            // :153
+            if (s) {
+                L = slot_logical(t, s);                                    // :156-166 (8-bit or 32-bit tier)
+                b.cov = L.cov; b.isFw = is_fw;                             // :168-169
+            }
+            if (b.cov == 0) ++missing;                                     // :172
+            else if (b.cov < cov_cutoff) ++missing;                        // :174
+            else {
+                bool no_left = false, no_right = false;
+                if (is_fw) {                                               // :178-193
+                    if (next < 4) { uint32_t v = L.e[next]; if (v) b.fw = v; else no_right = true; }
+                    if (prev < 4) { uint32_t v = L.e[4 + prev]; if (v) b.bw = v; else no_left = true; }
+                } else {                                                   // :194-210
+                    if (prev < 4) { uint32_t v = L.e[3 - prev]; if (v) b.fw = v; else no_left = true; }
+                    if (next < 4) { uint32_t v = L.e[4 + 3 - next]; if (v) b.bw = v; else no_right = true; }
+                }
+                if (no_left && no_right) ++edge_missing;                   // :211
+            }
+            ++total;                                                       // :216
+            if (PER_BASE && s) { b.pad[0] = 1; s_pb[16 * tid + i] = b; }
+        });
+        if (PER_BASE) {
+            __syncthreads();
+            const int64_t p0 = (int64_t)(tile * TILE_STARTS) - lo_valid;
+            for (int j = tid; j < TILE_STARTS; j += TILE_THREADS) {
+                kq_dbgbase b = s_pb[j];
+                if (b.pad[0]) { b.pad[0] = 0; per_base[p0 + j] = b; }
+            }
+        }
+        __syncthreads();
+    }
+    uint64_t a = block_sum(missing), b = block_sum(total), c = block_sum(edge_missing);
+    if (threadIdx.x == 0) {                                                // :223-225
+        if (a) atomicAdd(&counters[0], (unsigned long long)a);
+        if (b) atomicAdd(&counters[1], (unsigned long long)b);
+        if (c) atomicAdd(&counters[2], (unsigned long long)c);
+    }
+}
