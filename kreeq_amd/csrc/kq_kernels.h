@@ -66,10 +66,17 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(unsigned long long* a, 
     for (uint64_t i = lo; i < hi; ++i) sum += a[i];
     s_part[tid] = sum;
     __syncthreads();
-    if (tid == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < 1024; ++i) { unsigned long long v = s_part[i]; s_part[i] = run; run += v; }
-        *total = run;
+    if (tid < 64) {                              // wave 0 scans the 1024 partials, 16 per lane (a serial loop on one lane cost 13 us)
+        unsigned long long loc[16], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { loc[j] = s_part[tid * 16 + j]; tot += loc[j]; }
+        unsigned long long incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { unsigned long long nn = __shfl_up(incl, o, 64); if (tid >= o) incl += nn; }
+        unsigned long long run = incl - tot;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s_part[tid * 16 + j] = run; run += loc[j]; }
+        if (tid == 63) *total = incl;
     }
     __syncthreads();
     unsigned long long run = s_part[tid];

@@ -468,7 +468,7 @@ static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tile
 }
 // exclusive scan of n u64 on the device (in place); *total (device) receives the sum
 static void scan_u64(kq_handle* h, unsigned long long* a, uint64_t n, unsigned long long* sums_scratch, unsigned long long* total) {
-    if (n <= SCAN_CHUNK) {
+    if (n <= 2 * SCAN_CHUNK) {                     // one workgroup: up to 32 elements per thread
         hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, a, n, total);
         return;
     }
