@@ -124,7 +124,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_emit_write(const uint8_t* __re
 // counting pass (count matrix -> exclusive scan), because reservation atomics on a few hundred
 // shared cursors serialise per address (~11 ns each) and were the limiter of the first version.
 
-constexpr int P1_F = 4;                 // hist workgroups per scatter workgroup (hist is light on LDS)
+constexpr int P1_F = 1;                 // hist workgroups per scatter workgroup (the scatter grid is already 6 x the resident workgroups)
 constexpr uint32_t P2_UNIT = 4 * MS_TILE;   // records per work unit of a split level (never crosses a segment); 4 rounds: k_lv_scatter 357 us vs 384 us at 8, 401 us at 16, 430 us at 1
 
 // column of hist workgroup vb in the count matrix: the P1_F hist workgroups whose tiles one scatter
