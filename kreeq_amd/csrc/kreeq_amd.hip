@@ -75,9 +75,11 @@ struct kq_handle {
 
 static void marks_reset(kq_handle* h);
 
-static int grid_for(const kq_handle* h, uint64_t work_items, int per_block) {
+// grid-stride kernels: at most `per_cu` workgroups per CU.  8 = what is resident (kernels that flush per-workgroup
+// state at the end); the tile scanners take 32: the dispatcher balances the surplus (-4 % on k_lookup / k_count_direct)
+static int grid_for(const kq_handle* h, uint64_t work_items, int per_block, int per_cu = 8) {
     uint64_t blocks = (work_items + per_block - 1) / per_block;
-    uint64_t cap = (uint64_t)h->n_cu * 8;
+    uint64_t cap = (uint64_t)h->n_cu * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -731,7 +733,7 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
         PartCfg filt; plan_cfg(h, &filt);
         filt.filt_lo = h->filt_lo; filt.filt_hi = h->filt_hi;
         materialize(h);
-        hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, sub_len), 1)), dim3(TILE_THREADS), 0, h->stream,
+        hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, sub_len), 1, 32)), dim3(TILE_THREADS), 0, h->stream,
                            h->view(), ab, lead, sub_len, h->k, er, filt);
         HIPC(hipGetLastError());
     }
@@ -1015,7 +1017,7 @@ int kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uint
         }
         return KQ_OK;
     }
-    const dim3 grid(grid_for(h, n_tiles_of(lead, len), 1));
+    const dim3 grid(grid_for(h, n_tiles_of(lead, len), 1, 32));
     if (d_per_base) hipLaunchKernelGGL(k_lookup<true>, grid, dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len, h->k, (uint32_t)h->map_count,
                                        map_mask, (uint32_t)map_lo, (uint32_t)map_hi, cov_cutoff, d_per_base, (unsigned long long*)d_counters);
     else hipLaunchKernelGGL(k_lookup<false>, grid, dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len, h->k, (uint32_t)h->map_count,
