@@ -1111,3 +1111,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_lookup(TableView t, const uint
         if (c) atomicAdd(&counters[2], (unsigned long long)c);
     }
 }
+
+// export ordering: keys / indices of the compacted entries, then the entries gathered in key order
+__global__ __launch_bounds__(256) void k_entry_keys(const kq_entry* __restrict__ e, uint64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { keys[i] = e[i].key; idx[i] = (uint32_t)i; }
+}
+__global__ __launch_bounds__(256) void k_entry_gather(const kq_entry* __restrict__ in, const uint32_t* __restrict__ idx, uint64_t n, kq_entry* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = in[idx[i]];
+}
+

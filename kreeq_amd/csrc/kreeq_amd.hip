@@ -2,6 +2,7 @@
 // table sizing, partition planning and kernel launches.  The kernels live in kq_kernels.h (+ kq_device.h,
 // kq_partition.h).  gfx950 only; no CPU fallback anywhere in this library.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>       // device radix sort: only for the key order of kq_export (plumbing, not on the hot path)
 
 #include <algorithm>
 #include <cstdarg>
@@ -1136,9 +1137,29 @@ int kq_export(kq_handle* h, uint16_t map_lo, uint16_t map_hi, kq_entry* out, uin
     if (!rc && out) {
         if (n > cap) rc = fail(KQ_ERR_CAPACITY, "export buffer too small: need %llu, have %llu", n, (unsigned long long)cap);
         else if (n) {
-            e = hipMemcpy(out, d_out, n * sizeof(kq_entry), hipMemcpyDeviceToHost);
+            // key order on the device (radix sort of (key, index) + gather) when there is memory for it, else on the host
+            const kq_entry* src = d_out;
+            kq_entry* d_sorted = nullptr; uint64_t *d_k1 = nullptr, *d_k2 = nullptr; uint32_t *d_i1 = nullptr, *d_i2 = nullptr; void* d_tmp = nullptr;
+            size_t tmp_bytes = 0;
+            bool on_device = n < (1ull << 32) &&
+                hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k1, d_k2, d_i1, d_i2, (int64_t)n, 0, 2 * h->k, h->stream) == hipSuccess &&
+                hipMalloc((void**)&d_sorted, n * sizeof(kq_entry)) == hipSuccess && hipMalloc((void**)&d_k1, n * 8) == hipSuccess &&
+                hipMalloc((void**)&d_k2, n * 8) == hipSuccess && hipMalloc((void**)&d_i1, n * 4) == hipSuccess &&
+                hipMalloc((void**)&d_i2, n * 4) == hipSuccess && hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 8) == hipSuccess;
+            if (on_device) {
+                hipLaunchKernelGGL(k_entry_keys, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, d_out, n, d_k1, d_i1);
+                on_device = hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_k1, d_k2, d_i1, d_i2, (int64_t)n, 0, 2 * h->k, h->stream) == hipSuccess;
+                if (on_device) {
+                    hipLaunchKernelGGL(k_entry_gather, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, d_out, d_i2, n, d_sorted);
+                    on_device = hipStreamSynchronize(h->stream) == hipSuccess;
+                    src = d_sorted;
+                }
+            }
+            if (!on_device) { (void)hipGetLastError(); src = d_out; }
+            e = hipMemcpy(out, src, n * sizeof(kq_entry), hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = fail(KQ_ERR_HIP, "export copy failed: %s", hipGetErrorString(e));
-            else parallel_sort_entries(out, n);
+            else if (!on_device) parallel_sort_entries(out, n);
+            for (void* q : {(void*)d_sorted, (void*)d_k1, (void*)d_k2, (void*)d_i1, (void*)d_i2, d_tmp}) if (q) (void)hipFree(q);
         }
     }
     (void)hipFree(d_n);

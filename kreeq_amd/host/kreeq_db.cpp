@@ -186,19 +186,59 @@ void read_db(const std::string& db, std::vector<kq_entry>& out, DbIndex* idx_out
 void write_db_maps(const std::string& db, int map_count, int map_lo, int map_hi, const std::vector<kq_entry>& entries,
                    std::vector<kq_entry>& hc_out) {
     ::mkdir(db.c_str(), 0777);
-    std::vector<std::vector<std::pair<uint64_t, Val8>>> maps((size_t)(map_hi - map_lo));
-    for (const kq_entry& e : entries) {
-        const int m = (int)(e.key % (uint64_t)map_count);
-        if (m < map_lo || m >= map_hi) throw std::runtime_error("entry outside the map range being written");
-        Val8 v8{};
-        if (e.hc) {
-            hc_out.push_back(e);
-            v8.cov = 255;                                           // tombstone: "look in the 32-bit map" (:193, :233)
-        } else {
-            for (int w = 0; w < 4; ++w) { v8.fw[w] = (uint8_t)e.fw[w]; v8.bw[w] = (uint8_t)e.bw[w]; }
-            v8.cov = (uint8_t)e.cov;
-        }
-        maps[(size_t)(m - map_lo)].emplace_back(e.key, v8);
+    // bucket the entries by map in two parallel passes (count per chunk, then fill at the prefix offsets)
+    const size_t n_maps = (size_t)(map_hi - map_lo), n = entries.size();
+    unsigned hw0 = std::thread::hardware_concurrency();
+    const size_t nt0 = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, hw0 ? hw0 : 1), n / 65536 + 1));
+    std::vector<std::vector<uint64_t>> cnt(nt0, std::vector<uint64_t>(n_maps, 0));
+    std::vector<uint64_t> hc_cnt(nt0, 0);
+    std::atomic<bool> bad{false};
+    auto chunk = [&](size_t t) { return std::make_pair(n * t / nt0, n * (t + 1) / nt0); };
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt0; ++t) th.emplace_back([&, t] {
+            auto [a, b] = chunk(t);
+            for (size_t i = a; i < b; ++i) {
+                const int m = (int)(entries[i].key % (uint64_t)map_count);
+                if (m < map_lo || m >= map_hi) { bad = true; return; }
+                ++cnt[t][(size_t)(m - map_lo)];
+                hc_cnt[t] += entries[i].hc ? 1 : 0;
+            }
+        });
+        for (auto& x : th) x.join();
+    }
+    if (bad) throw std::runtime_error("entry outside the map range being written");
+    std::vector<std::vector<std::pair<uint64_t, Val8>>> maps(n_maps);
+    std::vector<std::vector<uint64_t>> off(nt0, std::vector<uint64_t>(n_maps, 0));
+    for (size_t m = 0; m < n_maps; ++m) {
+        uint64_t run = 0;
+        for (size_t t = 0; t < nt0; ++t) { off[t][m] = run; run += cnt[t][m]; }
+        maps[m].resize(run);
+    }
+    const size_t hc_base = hc_out.size();
+    std::vector<uint64_t> hc_off(nt0, 0);
+    { uint64_t run = 0; for (size_t t = 0; t < nt0; ++t) { hc_off[t] = run; run += hc_cnt[t]; } hc_out.resize(hc_base + run); }
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt0; ++t) th.emplace_back([&, t] {
+            auto [a, b] = chunk(t);
+            std::vector<uint64_t> pos = off[t];
+            uint64_t hpos = hc_base + hc_off[t];
+            for (size_t i = a; i < b; ++i) {
+                const kq_entry& e = entries[i];
+                const size_t m = (size_t)((int)(e.key % (uint64_t)map_count) - map_lo);
+                Val8 v8{};
+                if (e.hc) {
+                    hc_out[hpos++] = e;
+                    v8.cov = 255;                                   // tombstone: "look in the 32-bit map" (:193, :233)
+                } else {
+                    for (int w = 0; w < 4; ++w) { v8.fw[w] = (uint8_t)e.fw[w]; v8.bw[w] = (uint8_t)e.bw[w]; }
+                    v8.cov = (uint8_t)e.cov;
+                }
+                maps[m][pos[m]++] = std::make_pair(e.key, v8);
+            }
+        });
+        for (auto& x : th) x.join();
     }
     // one file per map: independent, so write them with a few threads
     unsigned hw = std::thread::hardware_concurrency();
