@@ -687,27 +687,31 @@ def test_merge_by_regions(kq, O, k, hint_dst, hint_src):
         assert dst.info()["slots_used"] == ref.summary()["distinct"]
 
 
-@pytest.mark.parametrize("hint,mid", [(5_000_000, 2), (5_870_000, 4), (40_000_000, 16), (5_870_000, 2048)])
-def test_narrow_middle_level(kq, O, hint, mid):
+@pytest.mark.parametrize("hint,mid,k", [(5_000_000, 2, 21), (5_870_000, 4, 21), (40_000_000, 16, 21), (5_870_000, 2048, 21),
+                                          (5_870_000, 4, 31), (5_000_000, 2, 32)])
+def test_narrow_middle_level(kq, O, hint, mid, k):
     """very large tables (>= 2048 regions per hash-prefix bucket) split bucket -> sub-bucket -> region; the
     threshold is lowered here so that small tables take the same three-pass route (1, 2 and 3 sub-bucket bits),
     through count, packed insert and the partitioned lookup"""
     import torch
 
     batch, genome = H.synth_reads(40000, 150, 200000, seed=611, err=0.01, n_rate=0.003)
-    gpu, cpu = kq.KreeqDB(21, 128, capacity_hint=hint), O.OracleDB(21, 128)
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=hint), O.OracleDB(k, 128)
     gpu.set_option("count_path", "partitioned")
     gpu.set_option("narrow_mid", mid)
     cut = batch.rfind(b"\n", 0, len(batch) // 2)
     gpu.count_batch(batch[:cut])
     cpu.count_batch(batch, threads=8)
-    # second half through the multi-GPU staging format (packed records -> converted -> narrow levels)
     rest = batch[cut + 1:]
-    t = torch.frombuffer(bytearray(rest), dtype=torch.uint8).cuda()
-    recs = torch.empty(len(rest), dtype=torch.int64, device="cuda")
-    src = kq.KreeqDB(21, 128)
-    counts = src.emit_packed_dev(t.data_ptr(), len(rest), 1, recs.data_ptr(), len(rest))
-    gpu.insert_packed_dev(recs.data_ptr(), int(counts[0]))
+    if k <= 28:
+        # second half through the multi-GPU staging format (packed records -> converted -> narrow levels)
+        t = torch.frombuffer(bytearray(rest), dtype=torch.uint8).cuda()
+        recs = torch.empty(len(rest), dtype=torch.int64, device="cuda")
+        src = kq.KreeqDB(k, 128)
+        counts = src.emit_packed_dev(t.data_ptr(), len(rest), 1, recs.data_ptr(), len(rest))
+        gpu.insert_packed_dev(recs.data_ptr(), int(counts[0]))
+    else:
+        gpu.count_batch(rest)                                       # 8-byte hash-remainder records through the same levels
     gpu.sync()
     assert gpu.summary(with_hist=True) == cpu.summary(with_hist=True)
     assert H.entries_equal(gpu.export(), cpu.export())
