@@ -471,6 +471,8 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
     constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
     const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
+    __shared__ uint64_t s_lut[64];            // edge indices -> u8x8 increment: one LDS read instead of ~8 VALU per record (-2.4 %)
+    if (threadIdx.x < 64) s_lut[threadIdx.x] = idx6_to_pack(threadIdx.x);     // visible after the first region's barrier
     __shared__ unsigned long long s_new, s_kmers;
     __shared__ unsigned int s_grp;
     // high-copy tier of this region, aggregated in LDS: a repeat k-mer with millions of instances
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec, aux) : TOP8 ? top8_hash(narrow_bucket, rec) : rec_hash<WIDE>(rec);
             if (active) {
                 key = key_of_hash(h, t.k);                                   // the mix is a bijection: no key in the record
-                pack = NARROW ? idx6_to_pack(aux >> 2) : TOP8 ? idx6_to_pack((uint32_t)rec & 63u)
+                pack = NARROW ? s_lut[(aux >> 2) & 63u] : TOP8 ? s_lut[(uint32_t)rec & 63u]
                      : WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
             }
             const uint64_t act = FOLD ? __ballot(active) : 0ull;
