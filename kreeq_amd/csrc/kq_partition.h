@@ -37,6 +37,9 @@ struct PartCfg {
     uint32_t filt_lo, filt_hi;   // count only k-mers whose map index key % map_count lies in [filt_lo, filt_hi)
     uint32_t raw_out;     // 1: WIDE records carry the raw key (kq_emit_partitioned_dev), else its table hash
     uint32_t narrow;      // 1: bin = top NARROW_CBITS hash bits (n_regions is a multiple of 2^NARROW_CBITS), FMT_NARROW records
+    uint32_t owner_sub;   // mode 1: each owner part is cut into 2^owner_sub sub-bins by lane id (a multisplit with a handful of
+                          // bins serialises its LDS rank atomics on a few addresses); the parts stay contiguous.  The histogram
+                          // and the scatter pass give a k-mer the same lane, hence the same sub-bin
     uint32_t sub_bits;    // narrow: > 0 = a middle level cuts each bucket into 2^sub_bits sub-buckets first (very large tables)
 };
 
@@ -276,7 +279,8 @@ __device__ __forceinline__ uint32_t p1_bin(const PartCfg& cfg, uint64_t key, uin
         if (m < cfg.filt_lo || m >= cfg.filt_hi) return cfg.n_coarse;
     }
     return cfg.mode == 0 ? (cfg.narrow ? (uint32_t)(h >> (64 - NARROW_CBITS)) : (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift))
-                         : owner_part_of(key, cfg.map_count, cfg.map_mask, cfg.n_coarse);
+                         : (owner_part_of(key, cfg.map_count, cfg.map_mask, cfg.n_coarse >> cfg.owner_sub) << cfg.owner_sub) |
+                           (threadIdx.x & ((1u << cfg.owner_sub) - 1u));      // by lane, not by key: grouping equal keys would cluster them for the receiver
 }
 
 }  // namespace kq

@@ -426,7 +426,7 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false
     cfg->raw_out = 0;
     // 5-byte records (FMT_NARROW): first split on the top 8 hash bits, which needs every bucket to own a
     // whole number of regions (kq_create rounds large tables to a multiple of 256 regions; doubling keeps it)
-    cfg->narrow = 0; cfg->sub_bits = 0;
+    cfg->narrow = 0; cfg->sub_bits = 0; cfg->owner_sub = 0;
     if (allow_narrow && (h->k <= (int)NARROW_MAX_K || h->k > PART_MAX_K) && cfg->n_regions >= (uint64_t)NB_MAX && cfg->n_regions % (1u << NARROW_CBITS) == 0) {
         const uint64_t rps = cfg->n_regions >> NARROW_CBITS;
         // one level bucket -> regions while a bucket has < mid_rps regions (the multisplit writes runs of 4096 / fan-out
@@ -815,16 +815,19 @@ int kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, int
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
     PartPlan p;
-    int rc = plan_alloc(h, &p, 0, n_tiles_of(lead, len), (uint32_t)n_parts);
+    uint32_t sb = 0;                                             // owner part x sub-bin by lane, see kq_emit_packed_dev
+    while (((uint32_t)n_parts << (sb + 1)) <= 256u && sb < 5) ++sb;
+    const uint32_t bins = (uint32_t)n_parts << sb;
+    int rc = plan_alloc(h, &p, 0, n_tiles_of(lead, len), bins);
     if (rc) return rc;
     PartCfg cfg = p.cfg;
-    cfg.mode = 1; cfg.n_coarse = (uint32_t)n_parts;
+    cfg.mode = 1; cfg.n_coarse = bins; cfg.owner_sub = sb;
     cfg.raw_out = 1;
     run_p1(h, &p, cfg, ab, lead, len, EmitRange{0, ~0ull}, d_keys, d_edges, AUX_EDGE_BYTE);      // WIDE records: key + reference edge byte
-    std::vector<unsigned long long> off((size_t)n_parts + 1);
+    std::vector<unsigned long long> off((size_t)bins + 1);
     HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n_parts; ++i) part_counts[i] = off[(size_t)i + 1] - off[(size_t)i];
+    for (int i = 0; i < n_parts; ++i) part_counts[i] = off[((size_t)i + 1) << sb] - off[(size_t)i << sb];
     return KQ_OK;
 }
 
@@ -841,15 +844,19 @@ int kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_pa
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
     PartPlan p;
-    int rc = plan_alloc(h, &p, 0, n_tiles_of(lead, len), (uint32_t)n_parts);
+    // up to 256 bins in all: owner part x sub-bin by lane (the order inside a part is unspecified anyway)
+    uint32_t sb = 0;
+    while (((uint32_t)n_parts << (sb + 1)) <= 256u && sb < 5) ++sb;
+    const uint32_t bins = (uint32_t)n_parts << sb;
+    int rc = plan_alloc(h, &p, 0, n_tiles_of(lead, len), bins);
     if (rc) return rc;
     PartCfg cfg = p.cfg;
-    cfg.mode = 1; cfg.n_coarse = (uint32_t)n_parts;
+    cfg.mode = 1; cfg.n_coarse = bins; cfg.owner_sub = sb;
     run_p1(h, &p, cfg, ab, lead, len, EmitRange{0, ~0ull}, d_recs, nullptr, AUX_IDX6);
-    std::vector<unsigned long long> off((size_t)n_parts + 1);
+    std::vector<unsigned long long> off((size_t)bins + 1);
     HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n_parts; ++i) part_counts[i] = off[(size_t)i + 1] - off[(size_t)i];
+    for (int i = 0; i < n_parts; ++i) part_counts[i] = off[((size_t)i + 1) << sb] - off[(size_t)i << sb];
     return KQ_OK;
 }
 
