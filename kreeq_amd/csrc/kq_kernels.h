@@ -136,7 +136,9 @@ __device__ __forceinline__ uint32_t p1_col(uint32_t vb, uint32_t g1) { return (v
 // bits (narrow).  The specialised modes keep the 16 unrolled steps free of wave-uniform branches.
 template <int BINMODE>
 __device__ __forceinline__ uint32_t p1_bin_of(const PartCfg& cfg, uint64_t key, uint64_t h) {
-    return BINMODE == 2 ? (uint32_t)(h >> (64 - NARROW_CBITS)) : BINMODE == 1 ? (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift) : p1_bin(cfg, key, h);
+    return BINMODE == 3 ? ((((((uint32_t)key & cfg.map_mask) * (cfg.n_coarse >> cfg.owner_sub)) >> __popc(cfg.map_mask)) << cfg.owner_sub) |
+                          (threadIdx.x & ((1u << cfg.owner_sub) - 1u)))         // owner rank x lane sub-bin; map_count a power of two, no filter
+         : BINMODE == 2 ? (uint32_t)(h >> (64 - NARROW_CBITS)) : BINMODE == 1 ? (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift) : p1_bin(cfg, key, h);
 }
 // KC != 0: k is the compile-time constant KC (the default k = 21 gets its own instantiation: every
 // k-dependent shift and mask of the 16 scan steps and of the hash folds to an immediate)

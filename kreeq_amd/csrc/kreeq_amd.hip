@@ -501,10 +501,12 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
                    uint8_t* out_aux, int aux_fmt) {
     // plain table split (no owner split, no map-range filter): branch-free bin functions
     const bool plain = cfg.mode == 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;
-    const int binmode = !plain ? 0 : cfg.narrow ? 2 : 1;
+    const bool owner_plain = cfg.mode == 1 && cfg.map_mask != 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;   // multi-GPU owner split
+    const int binmode = owner_plain ? 3 : !plain ? 0 : cfg.narrow ? 2 : 1;
 #define KQ_P1H(B, K) hipLaunchKernelGGL((k_p1_hist<B, K>), dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1)
     if (binmode == 2) { if (h->k == 21) KQ_P1H(2, 21); else KQ_P1H(2, 0); }
     else if (binmode == 1) { if (h->k == 31) KQ_P1H(1, 31); else KQ_P1H(1, 0); }
+    else if (binmode == 3) { if (h->k == 21) KQ_P1H(3, 21); else KQ_P1H(3, 0); }
     else KQ_P1H(0, 0);
 #undef KQ_P1H
     scan_u64(h, p->m1, (uint64_t)cfg.n_coarse * p->g1 * P1_F, p->sums, p->total);
@@ -516,6 +518,7 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     else if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1S(FMT_NARROW, 512, 2, 21); else if (plain) KQ_P1S(FMT_NARROW, 512, 2, 0); else KQ_P1S(FMT_NARROW, 512, 0, 0); }     // 256 buckets
     else if (out_aux && plain && h->k == 31) { if (small) KQ_P1S(FMT_WIDE, 512, 1, 31); else KQ_P1S(FMT_WIDE, NB_MAX, 1, 31); }   // the HiFi k
     else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512, 0, 0); else KQ_P1S(FMT_WIDE, NB_MAX, 0, 0); }
+    else if (owner_plain && !out_aux && small) { if (h->k == 21) KQ_P1S(FMT_PACK8, 512, 3, 21); else KQ_P1S(FMT_PACK8, 512, 3, 0); }
     else if (plain)   { if (small) KQ_P1S(FMT_PACK8, 512, 1, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 1, 0); }
     else              { if (small) KQ_P1S(FMT_PACK8, 512, 0, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 0, 0); }
 #undef KQ_P1S
