@@ -23,6 +23,12 @@ def random_batch(rng, n_reads, max_len, alphabet, sep):
     return sep.join(reads)
 
 
+def _copy_oracle(O, db, k):
+    c = O.OracleDB(k, 128)
+    c.import_entries(db.export())
+    return c
+
+
 @pytest.mark.parametrize("seed", range(150))
 def test_random_differential(seed):
     import kreeq_amd as kq
@@ -57,3 +63,17 @@ def test_random_differential(seed):
         assert np.array_equal(cg, cc)
         for f in ("fw", "bw", "cov", "isFw"):
             assert np.array_equal(pg[f], pc[f]), f
+        # the same counters through the region-wise lookup (P1 -> level -> k_lookup_regions)
+        gpu.set_option("lookup_path", "partitioned")
+        cr, _ = gpu.lookup_sequence(asm, cov_cutoff=cutoff, map_lo=a, map_hi=b_)
+        gpu.set_option("lookup_path", "auto")
+        assert np.array_equal(cr, cc)
+    # union by regions into a handle of another geometry == the table itself
+    other = kq.KreeqDB(k, 128, capacity_hint=int(rng.choice([0, 2_900_000])))
+    other.set_option("merge_path", "partitioned")
+    other.merge(gpu)
+    assert H.entries_equal(other.export(), cpu.export())
+    other.merge(gpu)                                                # every key present: counters double (saturating)
+    cpu.merge(cpu2 := _copy_oracle(O, cpu, k))
+    assert other.summary(with_hist=True) == cpu.summary(with_hist=True)
+    assert H.entries_equal(other.export(), cpu.export())
