@@ -1,34 +1,44 @@
 // kq_device.h -- device-side building blocks shared by all kernels (gfx950 only).
 //
 // HBM layout (see DESIGN.md "Data layout"):
-//   main table   : n_regions x REGION_SLOTS (2048) slots of 24 B  { u64 key; u64 edges8; u64 cov }
-//                  key   = canonical 2-bit k-mer (EMPTY = ~0, never a canonical key)
-//                  edges8= 8 packed u8 counters, byte e = edge e of include/kreeq.h:6-18
-//                          (e 0..3 = fw[A,C,G,T], 4..7 = bw[A,C,G,T]); only the first 254
-//                          instances of a k-mer add here, so no byte ever carries
-//                  cov   = exact instance count (u64; clamped to 2^32-1 when read out)
-//                  a key lives in region mulhi(mix(key), n_regions) and is probed linearly
+//   main table   : n_regions x REGION_SLOTS (2048) slots of 16 B  { u64 w0; u64 e8 }
+//                  w0  = rem | cov8 << 56.  rem = the 56 bits of the key's table hash that the slot's region does
+//                        not imply (slot_rem / slot_hash below); the canonical key itself is never stored: the hash
+//                        is a bijection of it, and only export / the high-copy tier need the key back.
+//                        cov8 = instance count 1..254, or 255 = "this k-mer lives in the high-copy tier" (the
+//                        reference's 8-bit tombstone, src/graph-builder.cpp:166-190).  w0 == 0 <=> empty slot
+//                        (an occupied slot has cov8 >= 1), so a cleared table is all zero bytes.
+//                  e8  = 8 packed u8 counters, byte e = edge e of include/kreeq.h:6-18
+//                        (e 0..3 = fw[A,C,G,T], 4..7 = bw[A,C,G,T]); only the first 254
+//                        instances of a k-mer add here, so no byte ever carries
+//                  a key lives in region mulhi(hash >> 32, n_regions) and is probed linearly
 //                  INSIDE that region only (regions are independent little tables: this is what
 //                  lets a workgroup own a region exclusively in the partitioned count path)
-//   high-copy    : power-of-two open-addressing table of 72 B { u64 key; u64 cnt[8] }: edge
-//                  counts of instances number 255.. of a k-mer (the reference's maps32 tier)
+//   high-copy    : power-of-two open-addressing table of 80 B { u64 key; u64 cov_hi; u64 cnt[8] }: the instances
+//                  number 255.. of a k-mer (the reference's maps32 tier): total cov = 254 + cov_hi, edge e =
+//                  e8 byte e + cnt[e]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace kq {
 
-constexpr uint64_t EMPTY_KEY = ~0ull;
+constexpr uint64_t EMPTY_KEY = ~0ull;          // empty marker of the high-copy table and of LDS region images (never a canonical key / a 56-bit remainder)
 constexpr uint32_t LARGEST = 4294967295u;      // include/kreeq.h:68
 constexpr uint32_t LOW_TIER_MAX = 254;         // src/graph-builder.cpp:166: the 255th instance overflows
 #ifndef KQ_REGION_SHIFT
 #define KQ_REGION_SHIFT 11
 #endif
 constexpr int REGION_SHIFT = KQ_REGION_SHIFT;
-constexpr uint32_t REGION_SLOTS = 1u << REGION_SHIFT;   // 2048 slots x 24 B = 48 KiB: three region images per CU's LDS
+constexpr uint32_t REGION_SLOTS = 1u << REGION_SHIFT;   // 2048 slots x 16 B = 32 KiB in HBM
+constexpr int COV_SHIFT = 56;
+constexpr uint64_t REM_MASK = (1ull << COV_SHIFT) - 1;
+constexpr uint64_t COV8_TOMB = 255;            // cov8 value of a k-mer whose count continues in the high-copy tier
+constexpr int HI_K = 29;                       // k >= HI_K: the hash has more than 56 bits, the region implies its top 8
 
-struct Slot { uint64_t key, edges8, cov; };
-struct HcSlot { uint64_t key; uint64_t cnt[8]; };
+struct Slot { uint64_t w0, e8; };
+struct HcSlot { uint64_t key; uint64_t cov_hi; uint64_t cnt[8]; };
+static_assert(sizeof(Slot) == 16 && sizeof(HcSlot) == 80, "table layouts");
 
 // device-resident state the host reads back after a sync
 struct DevState {
@@ -47,16 +57,17 @@ struct TableView {
     uint64_t hc_mask;       // capacity - 1
     DevState* st;
     uint32_t k;             // k-mer length: the table hash mixes exactly 2k bits
+    uint32_t rps;           // k >= HI_K: regions per top-8-bit hash bucket (n_regions / 256, exact); else 0
 };
 
 // Table hash = an INVERTIBLE mix of the key: one xorshift-multiply-xorshift round that is a bijection
 // on the 2k bits a canonical key occupies, returned left-aligned in 64 bits.  Region = top 32 bits
 // scaled to n_regions (< 2^32), in-region offset = the low 11 bits of the mixed value.  Because the mix
-// is a bijection, the records of the partitioned count path carry the mixed value instead of the key
-// (the hash is computed once, in the tile scanner; every later stage reads region / offset bits straight
-// from the record, and a stage may drop the bits its position already implies) and k_count_regions
-// recovers the key with the inverse (`key_of_hash`).  Region occupancy on k-mer sets is Poisson-like,
-// indistinguishable from murmur3's finaliser.
+// is a bijection, neither the records of the partitioned count path nor the table slots hold the key: they
+// carry (part of) the mixed value, computed once in the tile scanner; every later stage reads region / offset
+// bits straight from it, and a stage drops the bits its position already implies.  `key_of_hash` recovers the
+// key where the reference's view is needed (export, high-copy tier).  Region occupancy on k-mer sets is
+// Poisson-like, indistinguishable from murmur3's finaliser.
 constexpr uint64_t MIX_MUL = 0x9E3779B97F4A7C15ull;
 constexpr uint64_t mul_inverse(uint64_t a) {                 // a odd: Newton iteration doubles the correct bits
     uint64_t x = a;
@@ -79,6 +90,12 @@ __device__ __forceinline__ uint64_t key_of_hash(uint64_t h, uint32_t k) {
 }
 __device__ __forceinline__ uint64_t hash_region(uint64_t h, uint64_t n_regions) { return __umulhi((uint32_t)(h >> 32), (uint32_t)n_regions); }
 __device__ __forceinline__ uint32_t hash_offset(uint64_t h, uint32_t k) { return (uint32_t)(h >> (64 - 2 * k)) & (REGION_SLOTS - 1); }
+// The 56 hash bits a slot stores.  k <= 28: the hash has at most 56 significant bits (left-aligned: the low 8 are
+// zero).  k >= HI_K: tables have a multiple of 256 regions, so the top 8 hash bits are region / rps.
+__device__ __forceinline__ uint64_t slot_rem(uint64_t h, uint32_t k) { return k >= HI_K ? h & REM_MASK : h >> 8; }
+__device__ __forceinline__ uint64_t slot_hash(const TableView& t, uint64_t rem, uint64_t region) {
+    return t.k >= HI_K ? ((uint64_t)((uint32_t)region / t.rps) << COV_SHIFT) | rem : rem << 8;
+}
 
 __device__ __forceinline__ uint64_t mix64(uint64_t h) {
     h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
@@ -131,32 +148,15 @@ __device__ __forceinline__ Slot* region_of(const TableView& t, uint64_t h) {
     return t.slots + (hash_region(h, t.n_regions) << REGION_SHIFT);
 }
 
-// find-or-insert; returns nullptr when the region is full. *inserted = 1 for a new key.
-__device__ __forceinline__ Slot* table_upsert(const TableView& t, uint64_t key, uint32_t* inserted) {
-    const uint64_t h = table_hash(key, t.k);
-    Slot* base = region_of(t, h);
-    uint32_t off = hash_offset(h, t.k);
-    for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
-        Slot* s = base + ((off + probe) & (REGION_SLOTS - 1));
-        uint64_t cur = ld_relaxed(&s->key);
-        if (cur == EMPTY_KEY) {
-            cur = atomicCAS((unsigned long long*)&s->key, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-            if (cur == EMPTY_KEY) { *inserted = 1; return s; }
-        }
-        if (cur == key) return s;
-    }
-    return nullptr;
-}
-
-__device__ __forceinline__ const Slot* table_find(const TableView& t, uint64_t key) {
-    const uint64_t h = table_hash(key, t.k);
+__device__ __forceinline__ const Slot* table_find(const TableView& t, uint64_t h) {
     const Slot* base = region_of(t, h);
+    const uint64_t rem = slot_rem(h, t.k);
     uint32_t off = hash_offset(h, t.k);
     for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
         const Slot* s = base + ((off + probe) & (REGION_SLOTS - 1));
-        uint64_t cur = s->key;
-        if (cur == key) return s;
-        if (cur == EMPTY_KEY) return nullptr;
+        const uint64_t w = s->w0;
+        if (w == 0) return nullptr;
+        if ((w & REM_MASK) == rem) return s;
     }
     return nullptr;
 }
@@ -185,38 +185,60 @@ __device__ __forceinline__ const HcSlot* hc_find(const TableView& t, uint64_t ke
     }
     return nullptr;
 }
-
-// Add `cov` instances of `key` whose edge counts are e[0..7] (each <= cov).
-// Two-tier rule (restates src/graph-builder.cpp:165-205 order-independently): instances that keep
-// the k-mer's total <= 254 add to the packed u8 counters, everything else to the high-copy entry.
-// Because every edge counter <= cov, no u8 lane can exceed 254, and low + high is the exact sum.
-__device__ __forceinline__ bool table_add(const TableView& t, uint64_t key, uint64_t cov, uint64_t pack8,
-                                          const uint32_t* wide /*8 counters or nullptr*/, uint32_t* inserted) {
-    Slot* s = table_upsert(t, key, inserted);
-    if (!s) { atomicOr(&t.st->err_table_full, 1u); return false; }
-    uint64_t old = atomicAdd((unsigned long long*)&s->cov, (unsigned long long)cov);
-    if (old + cov <= LOW_TIER_MAX) {
-        if (pack8) atomicAdd((unsigned long long*)&s->edges8, (unsigned long long)pack8);
-        return true;
-    }
-    bool any = wide ? true : (pack8 != 0);
-    if (!any) return true;
-    HcSlot* hs = hc_upsert(t, key);
+// add `cov_hi` instances and the edge counts (packed u8x8, or 8 wide counters) to the high-copy entry of hash h
+__device__ __forceinline__ bool hc_add(const TableView& t, uint64_t h, uint64_t cov_hi, uint64_t pack8, const uint32_t* wide) {
+    HcSlot* hs = hc_upsert(t, key_of_hash(h, t.k));
     if (!hs) { atomicOr(&t.st->err_hc_full, 1u); return false; }
+    if (cov_hi) atomicAdd((unsigned long long*)&hs->cov_hi, (unsigned long long)cov_hi);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        uint64_t v = wide ? (uint64_t)wide[e] : ((pack8 >> (8 * e)) & 0xFF);
+        const uint64_t v = wide ? (uint64_t)wide[e] : ((pack8 >> (8 * e)) & 0xFF);
         if (v) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)v);
     }
     return true;
 }
 
+// Add `cov` instances of the k-mer with table hash `h` whose edge counts are pack8 (u8x8) or wide[0..7] (each
+// <= cov); wide != nullptr implies cov > 254.
+// Two-tier rule (restates src/graph-builder.cpp:165-205 order-independently): an add that keeps the k-mer's total
+// <= 254 goes to cov8 and the packed u8 counters; the add that crosses 254 turns cov8 into the tombstone 255 and,
+// like every later one, goes to the high-copy entry (cov_hi counts the instances beyond 254).  Because every edge
+// counter <= cov, no u8 lane can exceed 254, and low + high is the exact sum.
+// The count shares its word with the hash remainder, so the update is a CAS on w0 (claiming an empty slot and
+// counting its first instance in one step); the tombstone is sticky, so the high-copy tier needs no CAS.
+__device__ __forceinline__ bool table_add(const TableView& t, uint64_t h, uint64_t cov, uint64_t pack8,
+                                          const uint32_t* wide /*8 counters or nullptr*/, uint32_t* inserted) {
+    Slot* base = region_of(t, h);
+    const uint64_t rem = slot_rem(h, t.k);
+    const uint32_t off = hash_offset(h, t.k);
+    for (uint32_t probe = 0; probe < REGION_SLOTS; ++probe) {
+        Slot* s = base + ((off + probe) & (REGION_SLOTS - 1));
+        uint64_t w = ld_relaxed(&s->w0);
+        while (w == 0 || (w & REM_MASK) == rem) {
+            const uint64_t old = w >> COV_SHIFT;                       // 0: the slot is empty
+            if (old == COV8_TOMB) return hc_add(t, h, cov, pack8, wide);
+            const uint64_t sum = old + cov;
+            const bool low = sum <= LOW_TIER_MAX;
+            const uint64_t prev = atomicCAS((unsigned long long*)&s->w0, (unsigned long long)w,
+                                            (unsigned long long)(rem | ((low ? sum : COV8_TOMB) << COV_SHIFT)));
+            if (prev != w) { w = prev; continue; }                     // lost a race on this slot: look again
+            if (w == 0) *inserted = 1;
+            if (low) { if (pack8) atomicAdd((unsigned long long*)&s->e8, (unsigned long long)pack8); return true; }
+            return hc_add(t, h, sum - LOW_TIER_MAX, pack8, wide);
+        }
+    }
+    atomicOr(&t.st->err_table_full, 1u);
+    return false;
+}
+
 // logical (reference-visible) value of a slot: counters clamped to LARGEST
 struct Logical { uint32_t e[8]; uint32_t cov; };
-__device__ __forceinline__ Logical logical_of(const TableView& t, uint64_t key, uint64_t e8, uint64_t cov) {
+__device__ __forceinline__ Logical logical_of(const TableView& t, uint64_t h, uint64_t w0, uint64_t e8) {
     Logical L;
+    uint64_t cov = w0 >> COV_SHIFT;
+    const HcSlot* hs = (cov == COV8_TOMB) ? hc_find(t, key_of_hash(h, t.k)) : nullptr;
+    if (hs) cov = LOW_TIER_MAX + hs->cov_hi;
     L.cov = cov > LARGEST ? LARGEST : (uint32_t)cov;
-    const HcSlot* hs = (cov > LOW_TIER_MAX) ? hc_find(t, key) : nullptr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         uint64_t v = (e8 >> (8 * e)) & 0xFF;
@@ -225,7 +247,38 @@ __device__ __forceinline__ Logical logical_of(const TableView& t, uint64_t key, 
     }
     return L;
 }
-__device__ __forceinline__ Logical slot_logical(const TableView& t, const Slot* s) { return logical_of(t, s->key, s->edges8, s->cov); }
+// hash of the k-mer in slot s of table t (its region is implied by its index)
+__device__ __forceinline__ uint64_t slot_hash_at(const TableView& t, const Slot* s, uint64_t w0) {
+    return slot_hash(t, w0 & REM_MASK, (uint64_t)(s - t.slots) >> REGION_SHIFT);
+}
+__device__ __forceinline__ Logical slot_logical(const TableView& t, const Slot* s) {
+    const uint64_t w0 = s->w0;
+    return logical_of(t, slot_hash_at(t, s, w0), w0, s->e8);
+}
+
+// ---- LDS region image of the kernels that own a region (k_count_regions, k_merge_regions) ----------------------
+// Three u64 per slot: { rem (EMPTY_KEY when free), e8, cnt }.  cnt is the instance count as a full word, so LDS
+// atomics cannot wrap it; a slot that arrived as a tombstone starts at IMG_TOMB | 254, which every "old + n <= 254"
+// test fails, so its adds go to the high-copy tier.  img_store() turns cnt back into cov8 and hands the instances
+// beyond 254 that this pass added to the high-copy entry (one global atomic per high-copy k-mer and pass).
+constexpr uint64_t IMG_TOMB = 1ull << 63;
+__device__ __forceinline__ void img_load(uint64_t* img, uint32_t i, uint64_t w0, uint64_t e8) {
+    const uint64_t c = w0 >> COV_SHIFT;
+    img[3 * i] = w0 ? (w0 & REM_MASK) : EMPTY_KEY;
+    img[3 * i + 1] = e8;
+    img[3 * i + 2] = c == COV8_TOMB ? (IMG_TOMB | LOW_TIER_MAX) : c;
+}
+__device__ __forceinline__ ulonglong2 img_store(const TableView& t, const uint64_t* img, uint32_t i, uint64_t region) {
+    const uint64_t rem = img[3 * i], e8 = img[3 * i + 1], c = img[3 * i + 2];
+    if (rem == EMPTY_KEY) return make_ulonglong2(0ull, 0ull);
+    const uint64_t cnt = c & ~IMG_TOMB;
+    uint64_t cov8 = (c & IMG_TOMB) ? COV8_TOMB : cnt;
+    if (cnt > LOW_TIER_MAX) {
+        cov8 = COV8_TOMB;
+        hc_add(t, slot_hash(t, rem, region), cnt - LOW_TIER_MAX, 0, nullptr);
+    }
+    return make_ulonglong2(rem | (cov8 << COV_SHIFT), e8);
+}
 
 // ---- sequence tile scanner ---------------------------------------------------------------------
 // One workgroup (256 threads) walks tiles of TILE_STARTS k-mer start positions.  Per tile it loads

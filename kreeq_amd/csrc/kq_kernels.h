@@ -32,7 +32,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_count_direct(TableView t, cons
             if (m < filt.filt_lo || m >= filt.filt_hi) return;
         }
         uint32_t ins = 0;
-        if (table_add(t, key, 1, edge_pack(is_fw, prev, next), nullptr, &ins)) ++n_kmers;
+        if (table_add(t, table_hash(key, (uint32_t)k), 1, edge_pack(is_fw, prev, next), nullptr, &ins)) ++n_kmers;
         n_new += ins;
     });
     uint64_t a = block_sum(n_new), b = block_sum(n_kmers);
@@ -434,9 +434,10 @@ __global__ __launch_bounds__(1024) void k_scan_apply(unsigned long long* __restr
 }
 
 
-// P3: one workgroup per table region.  The region's slots (REGION_SLOTS x 24 B) are staged in LDS, all
-// records of the region are applied with LDS atomics (same two-tier rule as table_add), and the
-// image is streamed back.  Global atomics only for the rare high-copy tier and the two totals.
+// P3: one workgroup per table region.  The region's slots (REGION_SLOTS x 16 B in HBM) are staged in LDS as the
+// three-word image of kq_device.h (img_load), all records of the region are applied with LDS atomics (same
+// two-tier rule as table_add), and the image is streamed back (img_store).  Records and slots both hold hash
+// bits, so the walk never reconstructs a key.  Global atomics only for the rare high-copy tier and the two totals.
 #ifdef KQ_STAMPS   // diagnostic build only (never shipped): per-phase cycle sums of k_count_regions
 __device__ unsigned long long g_stamps[8];
 #define KQ_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
@@ -494,10 +495,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
         if (lo == hi) {                                                 // block-uniform
             if (!HOT && table_is_empty == 2) {    // lazy kq_clear: this launch initialises every region, also the ones without records
                 ulonglong2* g2 = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
-                for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) {
-                    const int w = 2 * i;
-                    g2[i] = make_ulonglong2(w % 3 == 0 ? EMPTY_KEY : 0ull, (w + 1) % 3 == 0 ? EMPTY_KEY : 0ull);
-                }
+                for (int i = tid; i < (int)REGION_SLOTS; i += P3_THREADS) g2[i] = make_ulonglong2(0ull, 0ull);
             }
             continue;
         }
@@ -512,12 +510,15 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
 #pragma unroll
             for (int e = 0; e < 8; ++e) s_hccnt[tid][e] = 0;
         }
-        uint4* gimg = reinterpret_cast<uint4*>(t.slots + (r << REGION_SHIFT));
-        uint4* limg = reinterpret_cast<uint4*>(s_img);
-        if (table_is_empty) {            // first batch after kq_create / kq_clear: the image is known, skip the 48 KiB read
+        ulonglong2* gimg = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
+        if (table_is_empty) {            // first batch after kq_create / kq_clear: the image is known, skip the 32 KiB read
             for (int i = tid; i < (int)(REGION_SLOTS * 3); i += P3_THREADS) s_img[i] = (i % 3 == 0) ? EMPTY_KEY : 0ull;
         } else {
-            for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+            ulonglong2 v[REGION_SLOTS / P3_THREADS];
+#pragma unroll
+            for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) v[j] = gimg[tid + j * P3_THREADS];     // all loads in flight, then the LDS writes
+#pragma unroll
+            for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) img_load(s_img, tid + j * P3_THREADS, v[j].x, v[j].y);
         }
         if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = P3_THREADS / 64; }
         __syncthreads();
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
         // its 64 lanes in dependent round trips (4-6 at load 0.5 when probing one slot at a time -- the walk
         // was bound by exactly that latency chain), now a quarter of it.  The snapshot is scanned in order; an
         // EMPTY slot is claimed with a CAS whose result decides (slots only ever go EMPTY -> key).
-        auto find_slot = [&](uint64_t key, uint64_t h) -> uint32_t {
+        auto find_slot = [&](uint64_t key /*56-bit hash remainder*/, uint64_t h) -> uint32_t {
             const uint32_t off = hash_offset(h, t.k);
             for (uint32_t base = 0; base < REGION_SLOTS; base += 4) {
                 uint32_t w[4];
@@ -555,7 +556,8 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             return REGION_SLOTS * 3;
         };
         // edge counts that no longer fit the u8 lanes: the region's LDS high-copy aggregation, global beyond 64 k-mers
-        auto add_wide = [&](uint64_t key, uint64_t h, const uint32_t (&e)[8]) {
+        auto add_wide = [&](uint64_t h, const uint32_t (&e)[8]) {
+            const uint64_t key = key_of_hash(h, t.k);                  // the high-copy tier is keyed by the canonical key
             int hslot = -1;
             uint32_t hp = (uint32_t)(h >> 40) & (HC_LDS - 1);
             for (int probe = 0; probe < HC_LDS; ++probe, hp = (hp + 1) & (HC_LDS - 1)) {
@@ -567,15 +569,12 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
 #pragma unroll
                 for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd(&s_hccnt[hslot][w], e[w]);
             } else {
-                HcSlot* hs = hc_upsert(t, key);
-                if (!hs) { atomicOr(&t.st->err_hc_full, 1u); return; }
-#pragma unroll
-                for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd((unsigned long long*)&hs->cnt[w], (unsigned long long)e[w]);
+                hc_add(t, h, 0, 0, e);
             }
         };
         // one record: `pack` holds its (at most two) edge bits, one per byte lane
-        auto apply1 = [&](uint64_t key, uint64_t h, uint64_t pack) {
-            const uint32_t w = find_slot(key, h);
+        auto apply1 = [&](uint64_t h, uint64_t pack) {
+            const uint32_t w = find_slot(slot_rem(h, t.k), h);
             if (w == REGION_SLOTS * 3) return;
             ++n_ok;
             const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], 1ull);
@@ -584,12 +583,11 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             uint32_t e1[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) e1[q] = (uint32_t)(pack >> (8 * q)) & 1u;
-            add_wide(key, h, e1);
+            add_wide(h, e1);
         };
-        // `cnt` folded instances of `key` with edge counts e[0..7] (each <= cnt)
-        auto apply = [&](uint64_t key, const uint32_t (&e)[8], uint32_t cnt) {
-            const uint64_t h = table_hash(key, t.k);
-            const uint32_t w = find_slot(key, h);
+        // `cnt` folded instances of the k-mer with hash h, edge counts e[0..7] (each <= cnt)
+        auto apply = [&](uint64_t h, const uint32_t (&e)[8], uint32_t cnt) {
+            const uint32_t w = find_slot(slot_rem(h, t.k), h);
             if (w == REGION_SLOTS * 3) return;
             n_ok += cnt;
             const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], (unsigned long long)cnt);
@@ -604,7 +602,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
                 atomicAdd((unsigned long long*)&s_img[w + 1], (unsigned long long)pack);
                 return;
             }
-            add_wide(key, h, e);
+            add_wide(h, e);
         };
         // Hot k-mers (repeats, homopolymers) put most lanes of a wave on ONE slot, batch after batch.
         // Lanes that share the first active lane's key are folded into a per-wave accumulator kept in
@@ -656,10 +654,10 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             bool active = i < hi;
             const uint64_t rec = cur_rec[q];
             const uint32_t aux = cur_aux[q];
-            uint64_t key = 0, pack = 0;
+            uint64_t pack = 0;
             const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec, aux) : TOP8 ? top8_hash(narrow_bucket, rec) : rec_hash<WIDE>(rec);
+            const uint64_t key = h;                                          // identity of the k-mer inside this kernel: its hash (a bijection of the key)
             if (active) {
-                key = key_of_hash(h, t.k);                                   // the mix is a bijection: no key in the record
                 pack = NARROW ? s_lut[(aux >> 2) & 63u] : TOP8 ? s_lut[(uint32_t)rec & 63u]
                      : WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
             }
@@ -688,7 +686,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
                     if (in_grp) active = false;
                 }
             }
-            if (active) apply1(key, h, pack);
+            if (active) apply1(h, pack);
           }
         }
         if (have_acc && (tid & 63) == 0) apply(acc_key, acc_e, acc_cnt);
@@ -708,7 +706,8 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             }
         }
         KQ_STAMP(2);                                                    // barrier (slowest wave) + high-copy flush
-        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) gimg[i] = limg[i];
+#pragma unroll
+        for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) gimg[tid + j * P3_THREADS] = img_store(t, s_img, tid + j * P3_THREADS, r);
         KQ_STAMP(3);                                                    // image store issue
         if (tid == 0) {
             if (s_new) atomicAdd(&t.st->slots_used, s_new);
@@ -726,12 +725,12 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
 // everything evaluateSegment needs (src/kreeq.cpp:145-216): the hash (-> key) and the indices of the
 // fw / bw edge the assembly continues with (edge_idx6: the strand mapping of :178-210 is already applied).
 template <int FMT>
-__global__ __launch_bounds__(P3_THREADS, 6) void k_lookup_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
+__global__ __launch_bounds__(P3_THREADS, 8) void k_lookup_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
                                                                    const unsigned long long* __restrict__ region_base, uint32_t narrow_rps,
                                                                    uint32_t cov_cutoff, unsigned long long* __restrict__ counters) {
     constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
     const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
-    __shared__ uint64_t s_img[REGION_SLOTS * 3];
+    __shared__ uint64_t s_img[REGION_SLOTS * 2];                        // the region as it lies in HBM (read-only here): 32 KiB, four workgroups per CU
     const int tid = threadIdx.x;
     uint32_t missing = 0, total = 0, edge_missing = 0;
     for (uint64_t r = blockIdx.x; r < t.n_regions; r += gridDim.x) {
@@ -739,7 +738,7 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_lookup_regions(TableView t, c
         if (lo == hi) continue;                                         // block-uniform
         const uint4* gimg = reinterpret_cast<const uint4*>(t.slots + (r << REGION_SHIFT));
         uint4* limg = reinterpret_cast<uint4*>(s_img);
-        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+        for (int i = tid; i < (int)REGION_SLOTS; i += P3_THREADS) limg[i] = gimg[i];
         __syncthreads();
         const uint32_t narrow_bucket = (NARROW || TOP8) ? (uint32_t)r / narrow_rps : 0u;
         const uint64_t last = hi - 1;
@@ -756,28 +755,31 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_lookup_regions(TableView t, c
             for (int q = 0; q < 2; ++q) {
                 if (base + (uint64_t)q * P3_THREADS + tid >= hi) continue;
                 const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec[q], aux[q]) : TOP8 ? top8_hash(narrow_bucket, rec[q]) : rec_hash<WIDE>(rec[q]);
-                const uint64_t key = key_of_hash(h, t.k);
+                const uint64_t rem = slot_rem(h, t.k);
                 const uint32_t idx6 = NARROW ? aux[q] >> 2 : TOP8 ? (uint32_t)rec[q] & 63u : WIDE ? aux[q] : (uint32_t)(rec[q] >> REC_EDGE_SHIFT) & 63u;
                 const uint32_t off = hash_offset(h, t.k);
-                uint32_t found = REGION_SLOTS * 3;
-                for (uint32_t pb = 0; pb < REGION_SLOTS && found == REGION_SLOTS * 3; pb += 4) {     // :153, four slots per LDS round trip
+                uint32_t found = REGION_SLOTS * 2;
+                for (uint32_t pb = 0; pb < REGION_SLOTS && found == REGION_SLOTS * 2; pb += 4) {     // :153, four slots per LDS round trip
                     uint32_t w[4];
                     uint64_t c[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { w[j] = 3u * ((off + pb + j) & (REGION_SLOTS - 1)); c[j] = s_img[w[j]]; }
+                    for (int j = 0; j < 4; ++j) { w[j] = 2u * ((off + pb + j) & (REGION_SLOTS - 1)); c[j] = s_img[w[j]]; }
                     bool stop = false;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (!stop && c[j] == key) { found = w[j]; stop = true; }
-                        if (!stop && c[j] == EMPTY_KEY) stop = true;
+                        if (!stop && c[j] != 0 && (c[j] & REM_MASK) == rem) { found = w[j]; stop = true; }
+                        if (!stop && c[j] == 0) stop = true;
                     }
                     if (stop) break;
                 }
                 uint64_t cov = 0, e8 = 0;
                 const HcSlot* hs = nullptr;
-                if (found != REGION_SLOTS * 3) {
-                    e8 = s_img[found + 1]; cov = s_img[found + 2];
-                    if (cov > LOW_TIER_MAX) hs = hc_find(t, key);                                    // :156-166 (32-bit tier)
+                if (found != REGION_SLOTS * 2) {
+                    e8 = s_img[found + 1]; cov = s_img[found] >> COV_SHIFT;
+                    if (cov == COV8_TOMB) {                                                          // :156-166 (32-bit tier)
+                        hs = hc_find(t, key_of_hash(h, t.k));
+                        if (hs) cov = LOW_TIER_MAX + hs->cov_hi;
+                    }
                 }
                 if (cov == 0 || cov < cov_cutoff) ++missing;                                         // :172-175
                 else {
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(256) void k_insert_records(TableView t, const uint6
     uint64_t n_ok = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t ins = 0;
-        if (table_add(t, keys[i], 1, edge_byte_to_pack(edges[i]), nullptr, &ins)) ++n_ok;
+        if (table_add(t, table_hash(keys[i], t.k), 1, edge_byte_to_pack(edges[i]), nullptr, &ins)) ++n_ok;
         n_new += ins;
     }
     uint64_t a = block_sum(n_new), b = block_sum(n_ok);
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(256) void k_insert_records(TableView t, const uint6
 }
 
 // import / union: add logical entries (kunion + mergeSubMaps, src/graph-builder.cpp:297-432)
-__device__ __forceinline__ void add_logical(const TableView& t, uint64_t key, const uint32_t* e, uint32_t cov,
+__device__ __forceinline__ void add_logical(const TableView& t, uint64_t h, const uint32_t* e, uint32_t cov,
                                             uint32_t& n_new, uint64_t& n_cov) {
     uint64_t pack = 0;
     bool fits = cov <= LOW_TIER_MAX;
@@ -824,7 +826,7 @@ __device__ __forceinline__ void add_logical(const TableView& t, uint64_t key, co
     for (int i = 0; i < 8; ++i) { if (e[i] > LOW_TIER_MAX) fits = false; pack |= (uint64_t)(e[i] & 0xFF) << (8 * i); }
     uint32_t ins = 0;
     // when the entry itself is beyond the low tier, table_add routes all of it to the wide counters
-    if (table_add(t, key, cov, fits ? pack : 0, fits ? nullptr : e, &ins)) n_cov += cov;
+    if (table_add(t, h, cov, fits ? pack : 0, fits ? nullptr : e, &ins)) n_cov += cov;
     n_new += ins;
 }
 __global__ __launch_bounds__(256) void k_import(TableView t, const kq_entry* __restrict__ in, uint64_t n) {
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(256) void k_import(TableView t, const kq_entry* __r
         uint32_t e[8];
 #pragma unroll
         for (int w = 0; w < 4; ++w) { e[w] = in[i].fw[w]; e[4 + w] = in[i].bw[w]; }
-        add_logical(t, in[i].key, e, in[i].cov, n_new, n_cov);
+        add_logical(t, table_hash(in[i].key, t.k), e, in[i].cov, n_new, n_cov);
     }
     uint64_t a = block_sum(n_new), b = block_sum(n_cov);
     if (threadIdx.x == 0) {
@@ -849,9 +851,11 @@ __global__ __launch_bounds__(256) void k_merge(TableView dst, TableView src) {
     const uint64_t n = src.n_regions << REGION_SHIFT;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const Slot* s = src.slots + i;
-        if (s->key == EMPTY_KEY) continue;
-        Logical L = slot_logical(src, s);
-        add_logical(dst, s->key, L.e, L.cov, n_new, n_cov);
+        const uint64_t w0 = s->w0;
+        if (w0 == 0) continue;
+        const uint64_t h = slot_hash_at(src, s, w0);
+        Logical L = logical_of(src, h, w0, s->e8);
+        add_logical(dst, h, L.e, L.cov, n_new, n_cov);
     }
     uint64_t a = block_sum(n_new), b = block_sum(n_cov);
     if (threadIdx.x == 0) {
@@ -869,13 +873,17 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, 
     const int tid = threadIdx.x;
     uint32_t n_new = 0;
     uint64_t n_cov = 0;
+    constexpr int SPT = REGION_SLOTS / P3_THREADS;
     for (uint64_t r = blockIdx.x; r < dst.n_regions; r += gridDim.x) {
-        uint4* gimg = reinterpret_cast<uint4*>(dst.slots + (r << REGION_SHIFT));
-        uint4* limg = reinterpret_cast<uint4*>(s_img);
+        ulonglong2* gimg = reinterpret_cast<ulonglong2*>(dst.slots + (r << REGION_SHIFT));
         if (dst_is_empty) {
             for (int i = tid; i < (int)(REGION_SLOTS * 3); i += P3_THREADS) s_img[i] = (i % 3 == 0) ? EMPTY_KEY : 0ull;
         } else {
-            for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) limg[i] = gimg[i];
+            ulonglong2 v[SPT];
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) v[j] = gimg[tid + j * P3_THREADS];
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) img_load(s_img, tid + j * P3_THREADS, v[j].x, v[j].y);
         }
         __syncthreads();
         // hash interval of dst region r (top 32 bits): [ceil(r 2^32 / R), ceil((r+1) 2^32 / R) - 1]
@@ -883,20 +891,18 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, 
         const uint32_t h_lo = (uint32_t)(((r << 32) + R - 1) / R), h_hi = (uint32_t)((((r + 1) << 32) + R - 1) / R - 1);
         const uint64_t s_lo = __umulhi(h_lo, (uint32_t)src.n_regions), s_hi = __umulhi(h_hi, (uint32_t)src.n_regions);
         for (uint64_t sr = s_lo; sr <= s_hi; ++sr) {
-            const Slot* sslots = src.slots + (sr << REGION_SHIFT);
-            // the whole source region in flight at once (three 8-byte loads per slot, unconditional): a load behind
-            // the key test would cost two dependent memory round trips per slot
-            constexpr int SPT = REGION_SLOTS / P3_THREADS;
-            uint64_t sk[SPT], se[SPT], sc[SPT];
+            const ulonglong2* sslots = reinterpret_cast<const ulonglong2*>(src.slots + (sr << REGION_SHIFT));
+            // the whole source region in flight at once (one 16-byte load per slot, unconditional)
+            ulonglong2 sv[SPT];
 #pragma unroll
-            for (int j = 0; j < SPT; ++j) { const Slot* sp = sslots + tid + j * P3_THREADS; sk[j] = sp->key; se[j] = sp->edges8; sc[j] = sp->cov; }
+            for (int j = 0; j < SPT; ++j) sv[j] = sslots[tid + j * P3_THREADS];
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
-                const uint64_t key = sk[j];
-                if (key == EMPTY_KEY) continue;
-                const uint64_t h = table_hash(key, dst.k);
+                if (sv[j].x == 0) continue;
+                const uint64_t h = slot_hash(src, sv[j].x & REM_MASK, sr);
                 if (hash_region(h, R) != r) continue;
-                const Logical L = logical_of(src, key, se[j], sc[j]);
+                const uint64_t rem = slot_rem(h, dst.k);
+                const Logical L = logical_of(src, h, sv[j].x, sv[j].y);
                 uint64_t pack = 0;
                 bool fits = L.cov <= LOW_TIER_MAX, any = false;
 #pragma unroll
@@ -908,16 +914,16 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, 
                     uint32_t ws[4];
                     uint64_t c[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { ws[j] = 3u * ((off + pb + j) & (REGION_SLOTS - 1)); c[j] = __hip_atomic_load(&s_img[ws[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                    for (int q = 0; q < 4; ++q) { ws[q] = 3u * ((off + pb + q) & (REGION_SLOTS - 1)); c[q] = __hip_atomic_load(&s_img[ws[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int q = 0; q < 4; ++q) {
                         if (w != REGION_SLOTS * 3) break;
-                        uint64_t cur = c[j];
+                        uint64_t cur = c[q];
                         if (cur == EMPTY_KEY) {
-                            cur = atomicCAS((unsigned long long*)&s_img[ws[j]], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-                            if (cur == EMPTY_KEY) { ++n_new; w = ws[j]; break; }
+                            cur = atomicCAS((unsigned long long*)&s_img[ws[q]], (unsigned long long)EMPTY_KEY, (unsigned long long)rem);
+                            if (cur == EMPTY_KEY) { ++n_new; w = ws[q]; break; }
                         }
-                        if (cur == key) w = ws[j];
+                        if (cur == rem) w = ws[q];
                     }
                 }
                 if (w == REGION_SLOTS * 3) { atomicOr(&dst.st->err_table_full, 1u); continue; }
@@ -925,16 +931,14 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, 
                 const uint64_t old = atomicAdd((unsigned long long*)&s_img[w + 2], (unsigned long long)L.cov);
                 if (fits && old + L.cov <= LOW_TIER_MAX) {
                     if (pack) atomicAdd((unsigned long long*)&s_img[w + 1], (unsigned long long)pack);
-                } else if (any) {                                       // beyond the u8 lanes: the wide counters (rare)
-                    HcSlot* hs = hc_upsert(dst, key);
-                    if (!hs) { atomicOr(&dst.st->err_hc_full, 1u); continue; }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (L.e[e]) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)L.e[e]);
+                } else if (any) {                                       // beyond the u8 lanes: the wide counters (rare); img_store adds the cov part
+                    hc_add(dst, h, 0, 0, L.e);
                 }
             }
         }
         __syncthreads();
-        for (int i = tid; i < (int)(REGION_SLOTS * 24 / 16); i += P3_THREADS) gimg[i] = limg[i];
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) gimg[tid + j * P3_THREADS] = img_store(dst, s_img, tid + j * P3_THREADS, r);
         __syncthreads();
     }
     const uint64_t a = block_sum(n_new), b = block_sum(n_cov);
@@ -944,15 +948,22 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, 
     }
 }
 // rehash into a bigger table (growth): exact move of physical state
-__global__ __launch_bounds__(256) void k_rehash(TableView dst, const Slot* __restrict__ old, uint64_t n_old) {
+__global__ __launch_bounds__(256) void k_rehash(TableView dst, TableView old) {
+    const uint64_t n_old = old.n_regions << REGION_SHIFT;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old; i += (uint64_t)gridDim.x * blockDim.x) {
-        const Slot s = old[i];
-        if (s.key == EMPTY_KEY) continue;
-        uint32_t ins = 0;
-        Slot* d = table_upsert(dst, s.key, &ins);
+        const Slot s = old.slots[i];
+        if (s.w0 == 0) continue;
+        const uint64_t h = slot_hash(old, s.w0 & REM_MASK, i >> REGION_SHIFT);
+        Slot* base = region_of(dst, h);
+        const uint64_t w0 = slot_rem(h, dst.k) | (s.w0 & ~REM_MASK);      // the count moves as it is (tombstone included)
+        const uint32_t off = hash_offset(h, dst.k);
+        Slot* d = nullptr;
+        for (uint32_t probe = 0; probe < REGION_SLOTS && !d; ++probe) {
+            Slot* c = base + ((off + probe) & (REGION_SLOTS - 1));
+            if (ld_relaxed(&c->w0) == 0 && atomicCAS((unsigned long long*)&c->w0, 0ull, (unsigned long long)w0) == 0ull) d = c;   // keys are unique: claim = done
+        }
         if (!d) { atomicOr(&dst.st->err_table_full, 1u); continue; }
-        d->edges8 = s.edges8;     // unique key per thread: plain stores
-        d->cov = s.cov;
+        d->e8 = s.e8;
     }
 }
 __global__ __launch_bounds__(256) void k_rehash_hc(TableView dst, const HcSlot* __restrict__ old, uint64_t n_old) {
@@ -960,6 +971,7 @@ __global__ __launch_bounds__(256) void k_rehash_hc(TableView dst, const HcSlot* 
         if (old[i].key == EMPTY_KEY) continue;
         HcSlot* d = hc_upsert(dst, old[i].key);
         if (!d) { atomicOr(&dst.st->err_hc_full, 1u); continue; }
+        d->cov_hi = old[i].cov_hi;
 #pragma unroll
         for (int e = 0; e < 8; ++e) d->cnt[e] = old[i].cnt[e];
     }
@@ -991,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_summary(TableView t, SummaryOut* out, u
     const uint64_t n = t.n_regions << REGION_SHIFT;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const Slot* s = t.slots + i;
-        if (s->key == EMPTY_KEY) continue;
+        if (s->w0 == 0) continue;
         Logical L = slot_logical(t, s);
         if (L.cov == 0) continue;                 // cannot happen (a key is inserted with cov >= 1)
         uniq += (L.cov == 1);                     // :250
@@ -1018,32 +1030,63 @@ __global__ __launch_bounds__(256) void k_summary(TableView t, SummaryOut* out, u
     }
 }
 
-// export: logical entries of maps [lo, hi)
+// export: logical entries of maps [lo, hi) (gfalibs dumpMap's input).  Tiles of 1024 slots; a workgroup reserves the
+// output range of a tile with ONE atomic (block-wide prefix of the per-thread counts), not one per entry.
 __global__ __launch_bounds__(256) void k_export(TableView t, uint32_t map_count, uint32_t lo, uint32_t hi,
                                                  kq_entry* out, uint64_t cap, unsigned long long* n_out) {
-    const uint64_t n = t.n_regions << REGION_SHIFT;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const Slot* s = t.slots + i;
-        const uint64_t key = s->key;
-        if (key == EMPTY_KEY) continue;
-        const uint32_t m = (uint32_t)(key % map_count);
-        if (m < lo || m >= hi) continue;
-        unsigned long long o = atomicAdd(n_out, 1ull);
-        if (out && o < cap) {
-            Logical L = slot_logical(t, s);
-            kq_entry e;
-            e.key = key;
+    __shared__ uint32_t s_wave[4];
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x;
+    const uint64_t n = t.n_regions << REGION_SHIFT;                    // a multiple of 1024
+    for (uint64_t tile = blockIdx.x; tile < n / 1024; tile += gridDim.x) {
+        uint64_t w0[4], e8[4], key[4];
+        uint32_t take = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { e.fw[w] = L.e[w]; e.bw[w] = L.e[4 + w]; }
-            e.cov = L.cov;
-            e.hc = L.cov > LOW_TIER_MAX;          // in maps32 iff total cov >= 255
-            out[o] = e;
+        for (int j = 0; j < 4; ++j) { const Slot* s = t.slots + tile * 1024 + j * 256 + tid; w0[j] = s->w0; e8[j] = s->e8; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            key[j] = 0;
+            if (w0[j] == 0) continue;
+            key[j] = key_of_hash(slot_hash(t, w0[j] & REM_MASK, (tile * 1024 + j * 256 + tid) >> REGION_SHIFT), t.k);
+            const uint32_t m = (uint32_t)(key[j] % map_count);
+            if (m >= lo && m < hi) take |= 1u << j;
         }
+        const uint32_t mine = __popc(take);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += v; }
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < (tid >> 6)) wave_base += s_wave[w]; total += s_wave[w]; }
+        if (tid == 0) s_base = total ? atomicAdd(n_out, (unsigned long long)total) : 0ull;
+        __syncthreads();
+        uint64_t o = s_base + wave_base + (incl - mine);
+        if (out) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!((take >> j) & 1u)) continue;
+                if (o < cap) {
+                    const uint64_t idx = tile * 1024 + j * 256 + tid;
+                    const Logical L = logical_of(t, slot_hash(t, w0[j] & REM_MASK, idx >> REGION_SHIFT), w0[j], e8[j]);
+                    kq_entry e;
+                    e.key = key[j];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { e.fw[w] = L.e[w]; e.bw[w] = L.e[4 + w]; }
+                    e.cov = L.cov;
+                    e.hc = L.cov > LOW_TIER_MAX;          // in maps32 iff total cov >= 255
+                    out[o] = e;
+                }
+                ++o;
+            }
+        }
+        __syncthreads();                                  // s_wave / s_base are reused by the next tile
     }
 }
 
 // K3: evaluateSegment (src/kreeq.cpp:143-219) over a whole sequence (segments = ACGT runs).
-// One random 24-B probe per k-mer: measured at 27.7 G lookups/s this is the part's random 64-B
+// One random 16-B probe per k-mer: measured at 27.7 G lookups/s this is the part's random 64-B
 // sector rate (a variant with 16 probes in flight per lane was not faster), so the kernel keeps the
 // simple one-k-mer-at-a-time form at full occupancy.  Per-base results are staged in LDS and
 // written out coalesced, and never read: a position is evaluated in exactly one map-range pass and
@@ -1077,9 +1120,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_lookup(TableView t, const uint
             kq_dbgbase b;
             b.fw = b.bw = b.cov = 0; b.isFw = 0; b.pad[0] = b.pad[1] = b.pad[2] = 0;
             Logical L;
-            const Slot* s = table_find(t, key);                            // :153
+            const uint64_t h = table_hash(key, (uint32_t)k);
+            const Slot* s = table_find(t, h);                              // :153
             if (s) {
-                L = slot_logical(t, s);                                    // :156-166 (8-bit or 32-bit tier)
+                L = logical_of(t, h, s->w0, s->e8);                        // :156-166 (8-bit or 32-bit tier)
                 b.cov = L.cov; b.isFw = is_fw;                             // :168-169
             }
             if (b.cov == 0) ++missing;                                     // :172

@@ -70,7 +70,11 @@ struct kq_handle {
     std::vector<std::pair<const char*, hipEvent_t>> marks;
     void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
 
-    TableView view() const { TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; v.k = (uint32_t)k; return v; }
+    TableView view() const {
+        TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; v.k = (uint32_t)k;
+        v.rps = k >= HI_K ? (uint32_t)(n_regions >> 8) : 0u;
+        return v;
+    }
     uint64_t n_slots() const { return n_regions << REGION_SHIFT; }
 };
 
@@ -99,17 +103,19 @@ static void clear_words(kq_handle* h, void* p, uint32_t words_per_slot, uint64_t
     const uint64_t n_pairs = n_slots * words_per_slot / 2;      // both table sizes make this exact
     hipLaunchKernelGGL(k_clear_slots, dim3(grid_for(h, n_pairs, 256)), dim3(256), 0, h->stream, (ulonglong2*)p, words_per_slot, n_pairs);
 }
+// an empty main table is all zero bytes (w0 == 0 <=> free slot)
+static void clear_main(kq_handle* h, Slot* p, uint64_t n_slots) { (void)hipMemsetAsync(p, 0, (size_t)n_slots * sizeof(Slot), h->stream); }
 // lazy kq_clear: give the slot array its empty image now (every table user except the partitioned count)
 static void materialize(kq_handle* h) {
     if (!h->slots_dirty) return;
-    clear_words(h, h->slots, 3, h->n_slots());
+    clear_main(h, h->slots, h->n_slots());
     h->slots_dirty = false;
 }
 static int alloc_main(kq_handle* h, uint64_t n_regions, Slot** out) {
     Slot* p = nullptr;
     size_t bytes = (size_t)(n_regions << REGION_SHIFT) * sizeof(Slot);
     HIPC(hipMalloc((void**)&p, bytes));
-    clear_words(h, p, 3, n_regions << REGION_SHIFT);
+    clear_main(h, p, n_regions << REGION_SHIFT);
     *out = p;
     return KQ_OK;
 }
@@ -117,7 +123,7 @@ static int alloc_hc(kq_handle* h, uint64_t cap, HcSlot** out) {
     HcSlot* p = nullptr;
     size_t bytes = (size_t)cap * sizeof(HcSlot);
     HIPC(hipMalloc((void**)&p, bytes));
-    clear_words(h, p, 9, cap);
+    clear_words(h, p, sizeof(HcSlot) / 8, cap);
     *out = p;
     return KQ_OK;
 }
@@ -148,9 +154,10 @@ static int grow_main(kq_handle* h, uint64_t need_slots) {
     if (rc) return rc == KQ_ERR_NOMEM ? fail(KQ_ERR_TABLE_FULL, "cannot grow k-mer table to %llu slots: out of device memory",
                                              (unsigned long long)want) : rc;
     Slot* old = h->slots; const uint64_t n_old = h->n_slots();
+    const TableView old_view = h->view();
     h->slots = fresh; h->n_regions = new_regions;
     if (h->slots_dirty) h->slots_dirty = false;     // lazily cleared table: nothing to move, and the fresh array is clean
-    else hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old, n_old);
+    else hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old_view);
     HIPC(hipStreamSynchronize(h->stream));
     HIPC(hipFree(old));
     return KQ_OK;
@@ -281,7 +288,9 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
         uint64_t slots = (uint64_t)((double)(capacity_hint ? capacity_hint : (1u << 20)) / 0.7);   // load <= 0.7 at the hinted size
         uint64_t regions = (slots + REGION_SLOTS - 1) >> REGION_SHIFT;
         if (regions < 16) regions = 16;
-        if (regions >= (uint64_t)NB_MAX) regions = (regions + 255) / 256 * 256;      // FMT_NARROW: 256 hash-prefix buckets of whole regions
+        // FMT_NARROW / FMT_TOP8 records: 256 hash-prefix buckets of whole regions; k >= HI_K needs it for every table
+        // (a slot drops the top 8 hash bits, which its region then implies)
+        if (regions >= (uint64_t)NB_MAX || k >= HI_K) regions = (regions + 255) / 256 * 256;
         if (regions >= (1ull << 19)) regions = (regions + 2047) / 2048 * 2048;         // ... of 8 sub-buckets of whole regions each
         rc = alloc_main(h, regions, &h->slots); if (rc) break;
         h->n_regions = regions;
@@ -315,7 +324,7 @@ int kq_clear(kq_handle* h) {
     if (!h) return fail(KQ_ERR_INVALID, "null handle");
     HIPC(hipSetDevice(h->device));
     h->slots_dirty = true;           // the 24 B/slot clear is folded into the next partitioned count (k_count_regions writes every region); anything else materialises it first
-    clear_words(h, h->hc, 9, h->hc_cap);
+    clear_words(h, h->hc, sizeof(HcSlot) / 8, h->hc_cap);
     HIPC(hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream));
     h->kmers_bound = 0;
     h->used_bound = 0;
@@ -583,7 +592,9 @@ static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint
     unsigned long long* hot = p->hot;
     (void)hipMemsetAsync(hot, 0, 8, h->stream);
     const dim3 grid((unsigned)std::min<uint64_t>(p->R, 1u << 30)), grid_hot(h->n_cu), block(P3_THREADS);   // one workgroup per region: dispatcher-balanced
-    const int empty = h->table_empty ? (h->slots_dirty ? 2 : 1) : 0;       // 2: also write the image of regions without records
+    // 1: the slot array holds the empty image (skip reading it); 2: logically empty but not initialised (lazy kq_clear):
+    // also write the image of regions without records.  A dirty array is never read, whatever table_empty says
+    const int empty = h->slots_dirty ? 2 : h->table_empty ? 1 : 0;
     const uint32_t rps = (p->fmt == FMT_NARROW || p->fmt == FMT_TOP8) ? (uint32_t)(p->R >> NARROW_CBITS) : 1u;
 #define KQ_P3(F) do { \
         hipLaunchKernelGGL((k_count_regions<F, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot, rps); \
@@ -593,7 +604,10 @@ static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint
     else if (sorted_aux) KQ_P3(FMT_WIDE);
     else KQ_P3(FMT_PACK8);
 #undef KQ_P3
-    h->slots_dirty = false;          // every region has been written
+    // only now (every failure path of the partition stages lies before this point): the table has content, and a lazily
+    // cleared slot array has been written in full
+    h->slots_dirty = false;
+    h->table_empty = false;
 }
 
 // can the record split reach every region of this table?  (5-byte records: up to 256 x 8 x 2047 regions, i.e.
@@ -729,14 +743,13 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
         }
         if (part) {
             rc = count_partitioned(h, ab, lead, sub_len, er);
-            h->table_empty = false;
             if (rc) return rc;
             continue;
         }
-        h->table_empty = false;
         PartCfg filt; plan_cfg(h, &filt);
         filt.filt_lo = h->filt_lo; filt.filt_hi = h->filt_hi;
         materialize(h);
+        h->table_empty = false;
         hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, sub_len), 1, 32)), dim3(TILE_THREADS), 0, h->stream,
                            h->view(), ab, lead, sub_len, h->k, er, filt);
         HIPC(hipGetLastError());
@@ -871,9 +884,7 @@ int kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n) {
     int rc = reserve(h, n, n);
     if (rc) return rc;
     if (!part_table_ok(h, true)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
-    rc = count_partitioned_records(h, d_recs, nullptr, AUX_IDX6, n, false);
-    h->table_empty = false;
-    return rc;
+    return count_partitioned_records(h, d_recs, nullptr, AUX_IDX6, n, false);
 }
 
 int kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d_edges, uint64_t n) {
@@ -883,12 +894,10 @@ int kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d
     int rc = reserve(h, n, n);
     if (rc) return rc;
     if ((h->count_path == 2 || (h->count_path == 0 && n >= (1u << 20))) && h->n_regions <= (1ull << 20)) {   // WIDE records: key + reference edge byte
-        rc = count_partitioned_records(h, d_keys, d_edges, AUX_EDGE_BYTE, n, true);
-        h->table_empty = false;
-        return rc;
+        return count_partitioned_records(h, d_keys, d_edges, AUX_EDGE_BYTE, n, true);
     }
-    h->table_empty = false;
     materialize(h);
+    h->table_empty = false;
     hipLaunchKernelGGL(k_insert_records, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, h->view(), d_keys, d_edges, n);
     HIPC(hipGetLastError());
     return KQ_OK;
@@ -1083,7 +1092,7 @@ int kq_merge(kq_handle* dst, kq_handle* src) {
     if (rc) return rc;
     // enough source entries to pay for streaming dst once: merge region by region in LDS; else per-entry atomics
     if (dst->merge_path == 2 || (dst->merge_path == 0 && src->st_host->slots_used * 64 >= dst->n_slots())) {
-        const int empty = dst->table_empty ? 1 : 0;
+        const int empty = (dst->table_empty || dst->slots_dirty) ? 1 : 0;     // a dirty (lazily cleared) array is never read
         hipLaunchKernelGGL(k_merge_regions, dim3((unsigned)std::min<uint64_t>(dst->n_regions, 1u << 30)), dim3(P3_THREADS), 0, dst->stream,
                            dst->view(), src->view(), empty);
         dst->slots_dirty = false;                       // every region image has been written
@@ -1091,8 +1100,8 @@ int kq_merge(kq_handle* dst, kq_handle* src) {
         HIPC(hipGetLastError());
         return kq_sync(dst);
     }
-    dst->table_empty = false;
     materialize(dst);
+    dst->table_empty = false;
     hipLaunchKernelGGL(k_merge, dim3(grid_for(dst, src->n_slots(), 256)), dim3(256), 0, dst->stream, dst->view(), src->view());
     HIPC(hipGetLastError());
     return kq_sync(dst);
@@ -1113,11 +1122,11 @@ int kq_import(kq_handle* h, const kq_entry* entries, uint64_t n) {
     }
     int rc = reserve(h, n, inst);
     if (rc) return rc;
-    h->table_empty = false;
     void* d = nullptr;
     rc = stage_in(h, entries, n * sizeof(kq_entry), &d);
     if (rc) return rc;
     materialize(h);
+    h->table_empty = false;
     hipLaunchKernelGGL(k_import, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, h->view(), (const kq_entry*)d, n);
     HIPC(hipGetLastError());
     return kq_sync(h);
