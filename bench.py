@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- k-mers/s of the count hot path on synthetic reads (BASELINE.json configs[1]).
+"""bench.py -- k-mers/s of the count hot path on synthetic reads.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one whole count job on one batch per GPU: clear the table, then hashSequences +
-processBuffers (K1+K2) over 1 M x 150 bp reads already resident in HBM (k=21).  With N>1 every
-rank counts its OWN 1 M reads (weak scaling) and routes records to the owning rank with one RCCL
-all-to-all (kreeq_amd/dist.py).  value = k-mer instances processed by all ranks / max-over-ranks
-wall time of the K timed steps.  One JSON line on rank 0.
+Default workload (N = 1) = BASELINE.json configs[2] at the largest scale whose table fits one MI355X next to the
+resident read set ("human-scale": G-Mbp iid genome, 30x 150 bp reads with 0.5 % substitutions generated on the
+device, k = 21, count, then validate the assembly = genome with 1e-4 substitutions).  The read set is cut into K
+equal batches; a "step" = one batch through the count hot path (hashSequences + processBuffers).  The timed region
+counts the K batches into ONE table that starts empty and ends with everything applied (kq_sync), inputs resident in
+HBM.  value = read k-mers / wall time.  The line also carries: `validate` (assembly lookup + QV), `configs1`
+(BASELINE configs[1], 1 M x 150 bp: steady state of several batches into one table and the empty-table figure that
+was round 1's headline), `lookup` and `union` (driver-timed, with their own roofline fractions), `cpu_baseline`.
+
+--workload cfg1 and every N > 1 run BASELINE configs[1] per GPU (weak scaling; N > 1 routes records to the owning
+rank with one RCCL all-to-all, kreeq_amd/dist.py).  One JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -27,8 +34,19 @@ N_READS = 1_000_000
 READ_LEN = 150
 GENOME_LEN = 5_000_000
 ERR = 0.005
+ASM_ERR = 1e-4
+COVERAGE = 30
 BYTES_PER_KMER = 35          # 1 B base + 17 B entry read + 17 B entry write
+BYTES_PER_LOOKUP = 18        # 1 B base + 17 B entry read
+BYTES_PER_UNION = 51         # 17 B read x 2 + 17 B write
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def qv(missing, total, k):
+    if total == 0:
+        return None
+    err = 1.0 - (1.0 - missing / total) ** (1.0 / k)        # src/kreeq.cpp:36-40
+    return float("inf") if err == 0 else -10.0 * math.log10(err)
 
 
 def main():
@@ -36,22 +54,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=N_READS, help="reads per GPU (default = BASELINE configs[1])")
+    ap.add_argument("--workload", choices=["human", "cfg1"], default="human")
+    ap.add_argument("--genome-mbp", type=float, default=1000.0, help="human workload: genome size (3000 = BASELINE configs[2] in full)")
+    ap.add_argument("--pending-bytes", type=int, default=-1, help="KQ_OPT_PENDING_BYTES (-1 auto, 0 = one table pass per slice)")
+    ap.add_argument("--reads", type=int, default=N_READS, help="cfg1: reads per GPU (default = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="human workload: skip the configs1 / lookup / union objects")
     ap.add_argument("--capacity", type=int, default=24_000_000,
-                    help="expected distinct k-mers per GPU (table = capacity/0.6 slots; the workload has 17.7 M)")
+                    help="cfg1: expected distinct k-mers per GPU (table = capacity/0.7 slots; the workload has 17.7 M)")
     ap.add_argument("--path", choices=["auto", "direct", "partitioned"], default="auto")
     ap.add_argument("-k", type=int, default=K, help="k-mer length (default 21 = BASELINE.json's metric)")
     ap.add_argument("--read-len", type=int, default=READ_LEN)
-    ap.add_argument("--sharded", action="store_true", help="with one GPU: still run the N>1 code path (owner split -> insert)")
+    ap.add_argument("--sharded", action="store_true", help="cfg1 with one GPU: still run the N>1 code path (owner split -> insert)")
     args = ap.parse_args()
-    K_, RL = args.k, args.read_len
 
     import torch
     import torch.distributed as dist
-
-    from kreeq_amd import synth
-    from kreeq_amd.dist import GpuEngine, ShardedCounter
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -65,7 +83,238 @@ def main():
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+    if world > 1 or args.sharded:
+        args.workload = "cfg1"
+    out = run_human(args, dev) if args.workload == "human" else run_cfg1(args, dev, world, rank, local_rank)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_human(args, dev):
+    import torch
+
+    from kreeq_amd import KreeqDB, synth
+
+    k, L = args.k, args.read_len
+    G = int(args.genome_mbp * 1e6)
+    steps, warmup = args.steps, args.warmup
+    batch_reads = max(1, int(G * COVERAGE / L) // steps)
+    n_reads = batch_reads * steps
+    kmers_per_step = batch_reads * (L - k + 1)
+
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    genome = synth.genome_dev(G, dev, seed=1)
+    asm_codes, n_sub = synth.mutate_dev(genome, ASM_ERR, seed=3)
+    assembly = synth.ascii_dev(asm_codes)
+    del asm_codes
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2)
+    batches = [synth.reads_dev(genome, batch_reads, L, gen, err=ERR) for _ in range(steps)]
+    del genome
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+
+    # distinct k-mers: the genome's + ~k novel ones per read error (jellyfish -s style bound, 10 % margin)
+    hint = int(1.1 * (G + n_reads * L * ERR * k))
+    db = KreeqDB(k, 128, device=dev.index, capacity_hint=hint)
+    db.set_option("trust_capacity", 1)
+    db.set_option("count_path", args.path)
+    db.set_option("pending_bytes", args.pending_bytes)
+    db.set_stream(stream.cuda_stream)
+
+    def count(i):
+        t = batches[i % steps]
+        db.count_batch_dev(t.data_ptr(), t.numel())
+
+    for i in range(warmup):              # sizes the scratch and the pending-set arena, warms the code objects
+        count(i)
+    db.sync()
+    db.clear()
+    torch.cuda.synchronize(dev)
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(steps):
+        count(i)
+    db.sync()                            # applies what is still pending: the table is complete when the clock stops
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+
+    summ = db.summary()
+    assert summ["total"] == kmers_per_step * steps, (summ, kmers_per_step, steps)
+    info = db.info()
+    assert info["slots_used"] == summ["distinct"], (info, summ)
+
+    # validate: the assembly's k-mers against the table (DBG::validateSequences)
+    ctr = torch.zeros(3, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    tv = time.perf_counter()
+    db.lookup_sequence_dev(assembly.data_ptr(), assembly.numel(), ctr.data_ptr())
+    torch.cuda.synchronize(dev)
+    t_val = time.perf_counter() - tv
+    c = ctr.cpu().tolist()
+    assert c[1] == G - k + 1, c
+
+    value = kmers_per_step * steps / dt
+    ms_kernel = dev_ms / steps
+    achieved = kmers_per_step * BYTES_PER_KMER / (ms_kernel * 1e-3) / 1e9
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        tj = json.load(open(tp))
+        if tj.get("workload") == f"human-{int(args.genome_mbp)}mbp-{steps}steps":
+            traffic = tj.get("hbm_bytes_per_launch")
+    out = {
+        "metric": f"distinct+total k-mers/sec at k={k} (count path)", "value": value, "unit": "k-mers/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"configs[2] shape at {G / 3e9:.3f} scale: {G // 1_000_000} Mbp iid genome, {COVERAGE}x {L} bp reads "
+                               f"({n_reads} reads, {ERR * 100:g} % substitutions, generated on the device), k={k}, count in {steps} batches + validate, 1 GPU",
+                   "genome_bp": G, "reads": n_reads, "reads_per_step": batch_reads, "error_rate": ERR, "table_capacity_kmers": hint,
+                   "table_bytes": info["table_bytes"], "table_passes": info["table_passes"], "pending_bytes": args.pending_bytes,
+                   "count_path": args.path, "sharding": "none"},
+        "total_kmers_per_step": kmers_per_step, "distinct_kmers": summ["distinct"], "distinct_kmers_per_s": summ["distinct"] / dt,
+        "summary": summ,
+        "validate": {"assembly_kmers": c[1], "substitutions": n_sub, "missing": c[0], "edge_missing": c[2], "ms": t_val * 1e3,
+                     "kmers_per_s": c[1] / t_val, "qv_merqury": qv(c[0], c[1], k), "qv_kreeq": qv(c[0] + c[2], c[1], k),
+                     "roofline_frac": c[1] * BYTES_PER_LOOKUP / t_val / 1e9 / HBM_PEAK_GBS},
+        "roofline": {"bound": "hbm", "kernel": "count launch set per batch: k_p1_hist+k_p1_scatter+k_lv_hist+k_lv_scatter (x levels) per slice, "
+                                               "k_count_regions per table pass (+scans)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": ms_kernel},
+    }
+    if not args.no_cpu_baseline:
+        sample = min(batch_reads, 1_000_000)
+        out["cpu_baseline"] = cpu_baseline(batches[0][:sample * (L + 1) - 1].cpu().numpy(), k, L)
+    del db, batches, assembly
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    if not args.no_extras:
+        out.update(extras_cfg1(dev, stream))
+    return out
+
+
+def extras_cfg1(dev, stream):
+    """BASELINE configs[1] (1 M x 150 bp, k = 21) on the same GPU: count (steady state and empty table), lookup, union --
+    each timed with HIP events on the stream the library launches on."""
+    import torch
+
+    from kreeq_amd import KreeqDB, synth
+
+    g = synth.genome_codes(GENOME_LEN, seed=1)
+    batches = [torch.from_numpy(synth.reads_batch(g, N_READS, READ_LEN, seed=s, err=ERR)).to(dev) for s in (2, 3, 4, 5)]
+    asm = torch.from_numpy(synth.codes_to_ascii(synth.mutate(g, ASM_ERR, seed=3))).to(dev)
+    kmers = N_READS * (READ_LEN - K + 1)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) / reps
+
+    res = {}
+    # count, steady state: four different batches into one table, then clear
+    db = KreeqDB(K, 128, device=dev.index, capacity_hint=70_000_000)
+    db.set_option("trust_capacity", 1)
+    db.set_stream(stream.cuda_stream)
+
+    def four():
+        db.clear()
+        for t in batches:
+            db.count_batch_dev(t.data_ptr(), t.numel())
+        db.sync()
+    ms4 = timed(four, 5)
+    s4 = db.summary()
+    assert s4["total"] == 4 * kmers
+    # the same with one table pass per batch (what a caller that reads the table after every batch gets)
+    db.set_option("pending_bytes", 0)
+    ms4_each = timed(four, 5)
+    del db
+    # count, empty table: clear + one batch (round 1's headline configuration)
+    db = KreeqDB(K, 128, device=dev.index, capacity_hint=24_000_000)
+    db.set_option("trust_capacity", 1)
+    db.set_stream(stream.cuda_stream)
+
+    def one():
+        db.clear()
+        db.count_batch_dev(batches[0].data_ptr(), batches[0].numel())
+        db.sync()
+    ms1 = timed(one, 10)
+    s1 = db.summary()
+    assert s1["total"] == kmers
+    res["configs1"] = {"workload": "synthetic 1000000 x 150 bp reads, k=21, count-only (configs[1])",
+                       "steady_state": {"what": "4 different batches into one table (70 M-entry hint), one table pass", "ms_per_batch": ms4 / 4,
+                                        "kmers_per_s": kmers / (ms4 / 4 * 1e-3), "roofline_frac": kmers * BYTES_PER_KMER / (ms4 / 4 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "distinct": s4["distinct"]},
+                       "steady_state_pass_per_batch": {"ms_per_batch": ms4_each / 4, "kmers_per_s": kmers / (ms4_each / 4 * 1e-3)},
+                       "empty_table": {"what": "clear + one batch (round 1's headline)", "ms_per_batch": ms1, "kmers_per_s": kmers / (ms1 * 1e-3),
+                                       "roofline_frac": kmers * BYTES_PER_KMER / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "distinct": s1["distinct"]}}
+    # lookup: the 130 M read k-mers and the 5 Mbp assembly against the 17.7 M-entry table (counters only)
+    ctr = torch.zeros(3, dtype=torch.int64, device=dev)
+    ms_lr = timed(lambda: db.lookup_sequence_dev(batches[0].data_ptr(), batches[0].numel(), ctr.data_ptr()), 5)
+    ctr.zero_()
+    db.lookup_sequence_dev(asm.data_ptr(), asm.numel(), ctr.data_ptr())
+    torch.cuda.synchronize(dev)
+    ca = ctr.cpu().tolist()
+    pb = torch.zeros(batches[0].numel() * 16, dtype=torch.uint8, device=dev)
+    ms_pb = timed(lambda: db.lookup_sequence_dev(batches[0].data_ptr(), batches[0].numel(), ctr.data_ptr(), per_base_ptr=pb.data_ptr()), 3)
+    del pb
+    res["lookup"] = {"workload": "130 M read k-mers against the configs[1] table (17.7 M entries), QV counters only", "ms": ms_lr,
+                     "kmers_per_s": kmers / (ms_lr * 1e-3), "bytes_per_kmer": BYTES_PER_LOOKUP,
+                     "roofline_frac": kmers * BYTES_PER_LOOKUP / (ms_lr * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "per_base": {"ms": ms_pb, "kmers_per_s": kmers / (ms_pb * 1e-3), "bytes_per_kmer": BYTES_PER_LOOKUP + 16,
+                                  "roofline_frac": kmers * (BYTES_PER_LOOKUP + 16) / (ms_pb * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "assembly_5mbp": {"missing": ca[0], "total": ca[1], "edge_missing": ca[2], "qv_merqury": qv(ca[0], ca[1], K)}}
+    # union: a second database of the same size merged into a copy of the first
+    other = KreeqDB(K, 128, device=dev.index, capacity_hint=24_000_000)
+    other.set_stream(stream.cuda_stream)
+    other.count_batch_dev(batches[1].data_ptr(), batches[1].numel())
+    other.sync()
+    n_other = other.summary()["distinct"]
+    times = []
+    for _ in range(3):
+        dst = KreeqDB(K, 128, device=dev.index, capacity_hint=40_000_000)
+        dst.set_stream(stream.cuda_stream)
+        dst.merge(db)
+        torch.cuda.synchronize(dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        dst.merge(other)
+        b.record()
+        torch.cuda.synchronize(dev)
+        times.append(a.elapsed_time(b))
+        n_union = dst.summary()["distinct"]
+        del dst
+    ms_u = min(times[1:])
+    res["union"] = {"workload": "kq_merge of a 17.7 M-entry database into a filled 17.7 M-entry one (40 M-entry table)", "ms": ms_u,
+                    "entries": n_other, "entries_per_s": n_other / (ms_u * 1e-3), "bytes_per_entry": BYTES_PER_UNION,
+                    "roofline_frac": n_other * BYTES_PER_UNION / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS, "union_distinct": n_union}
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_cfg1(args, dev, world, rank, local_rank):
+    """BASELINE configs[1] per GPU: clear + one batch per step (weak scaling for N > 1)."""
+    import torch
+    import torch.distributed as dist
+
+    from kreeq_amd import synth
+    from kreeq_amd.dist import GpuEngine, ShardedCounter
+
+    K_, RL = args.k, args.read_len
     # synthetic input: same genome everywhere, a different read shard per rank
     genome = synth.genome_codes(GENOME_LEN, seed=1)
     reads_np = synth.reads_batch(genome, args.reads, RL, seed=2 + 1000 * rank, err=ERR)
@@ -86,6 +335,7 @@ def main():
     def step():
         engine.clear()
         counter.count_batch(reads)
+        engine.flush()
 
     def barrier():
         if world > 1:
@@ -96,13 +346,14 @@ def main():
         step()
     barrier()
 
-    # per-step kernel time of the dominant kernel via HIP events on the stream it is launched on
+    # per-step kernel time via HIP events on the stream the kernels are launched on
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         engine.clear()
         ev[i][0].record()
         counter.count_batch(reads)
+        engine.flush()
         ev[i][1].record()
     barrier()
     dt = time.perf_counter() - t0
@@ -124,40 +375,32 @@ def main():
     # correctness guard inside the bench: totals must match the closed form
     summ = counter.summary()
     assert summ["total"] == kmers_per_rank * world, (summ, kmers_per_rank, world)
-
-    if rank == 0:
-        total_kmers = kmers_per_rank * world * args.steps
-        value = total_kmers / dt
-        launch_kmers = kmers_per_rank            # k-mers one launch of the dominant kernel processes
-        achieved = launch_kmers * BYTES_PER_KMER / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and world == 1 and args.reads == N_READS:
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-        out = {
-            "metric": f"distinct+total k-mers/sec at k={K_} (count path)", "value": value, "unit": "k-mers/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.reads} x {RL} bp reads per GPU, k={K_}, count-only" + (" (configs[1])" if (K_, RL, args.reads) == (K, READ_LEN, N_READS) else ""),
-                       "genome_bp": GENOME_LEN, "error_rate": ERR, "table_capacity_kmers": args.capacity, "count_path": args.path, "sharding": f"bucket x{world}" if world > 1 else "none"},
-            "total_kmers_per_step": kmers_per_rank * world, "distinct_kmers": summ["distinct"],
-            "distinct_kmers_per_s": summ["distinct"] * args.steps / dt,
-            "roofline": {"bound": "hbm", "kernel": ("count_batch launch set: k_p1_hist+k_p1_scatter+k_lv_hist+k_lv_scatter+k_count_regions (+scans)" if args.path != "direct"
-                                                    else "k_count_direct") if world == 1 and not args.sharded else "owner split (k_p1_*) + all_to_all + k_lv_* + k_count_regions",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": kern_ms, "stage_ms": stages},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(reads_np, K_, RL)
-        print(json.dumps(out), flush=True)
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    total_kmers = kmers_per_rank * world * args.steps
+    value = total_kmers / dt
+    achieved = kmers_per_rank * BYTES_PER_KMER / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": f"distinct+total k-mers/sec at k={K_} (count path)", "value": value, "unit": "k-mers/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.reads} x {RL} bp reads per GPU, k={K_}, count-only, clear + one batch per step" + (" (configs[1])" if (K_, RL, args.reads) == (K, READ_LEN, N_READS) else ""),
+                   "genome_bp": GENOME_LEN, "error_rate": ERR, "table_capacity_kmers": args.capacity, "count_path": args.path, "sharding": f"bucket x{world}" if world > 1 else "none"},
+        "total_kmers_per_step": kmers_per_rank * world, "distinct_kmers": summ["distinct"],
+        "distinct_kmers_per_s": summ["distinct"] * args.steps / dt,
+        "roofline": {"bound": "hbm", "kernel": ("count_batch launch set: k_p1_hist+k_p1_scatter+k_lv_hist+k_lv_scatter+k_count_regions (+scans)" if args.path != "direct"
+                                                else "k_count_direct") if world == 1 and not args.sharded else "owner split (k_p1_*) + all_to_all + k_lv_* + k_count_regions",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": kern_ms, "stage_ms": stages},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(reads_np, K_, RL)
+    return out
 
 
 def cpu_baseline(reads_np, k=K, read_len=READ_LEN):
     """The CPU restatement of the reference algorithm (oracle/, kind "port": the reference itself
-    cannot be built -- gfalibs is absent) timed on this host's cores on the same batch."""
+    cannot be built -- gfalibs is absent) timed on this host's cores on a bounded sample of the same reads."""
     from oracle import oracle as O
 
     try:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KQ_ABI_VERSION 1
+#define KQ_ABI_VERSION 2
 
 typedef enum {
     KQ_OK = 0,
@@ -83,6 +83,7 @@ typedef struct {
     uint64_t hc_used;         /* occupied high-copy side-table slots                          */
     uint64_t hc_total;
     uint64_t table_bytes;     /* HBM bytes held by table + side table                         */
+    uint64_t table_passes;    /* region-wise passes over the table so far (see KQ_OPT_PENDING_BYTES) */
 } kq_info;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -117,12 +118,22 @@ void* kq_get_stream(kq_handle* h);
  *   KQ_OPT_MERGE_PATH      kq_merge into this handle: 0 = auto, 1 = one atomic add per source entry, 2 = region by
  *                          region (destination images staged in LDS, both tables streamed once)
  *   KQ_OPT_NARROW_MID      (tuning / tests) regions per hash-prefix bucket from which the record split of the
- *                          partitioned paths gets a middle level (default 2048, i.e. tables above 12.9 GB) */
+ *                          partitioned paths gets a middle level (default 2048, i.e. tables above 8.6 GB)
+ *   KQ_OPT_PENDING_BYTES   the partitioned count keeps the region-sorted records of a slice PENDING in an arena of at most
+ *                          this many bytes of HBM and applies all pending sets in one pass over the table (when the arena
+ *                          is full, and before anything reads the table: kq_sync, summary, lookup, export, merge ...), so
+ *                          that a large table is streamed once per arena-full of records rather than once per slice.
+ *                          -1 = automatic (default: a few times the table, at most half of the free HBM), 0 = apply every
+ *                          slice at once.  Results never depend on it (counting is commutative). */
 enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4, KQ_OPT_PROFILE = 5,
-       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8 };
+       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8, KQ_OPT_PENDING_BYTES = 9,
+       KQ_OPT_TEST_FAIL_PLAN = 100 /* failure-path tests only: the next partition plan of a count fails with KQ_ERR_NOMEM */ };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_get_profile(kq_handle* h, char* buf, uint64_t cap);
 int  kq_sync(kq_handle* h);
+/* Enqueue the table pass that applies all pending record sets (KQ_OPT_PENDING_BYTES); asynchronous, no-op when
+ * nothing is pending.  kq_sync() and every call that reads the table do this themselves. */
+int  kq_flush(kq_handle* h);
 int  kq_get_info(kq_handle* h, kq_info* out);
 const char* kq_last_error(void);
 int  kq_abi_version(void);
@@ -134,7 +145,8 @@ int  kq_device_available(void);
 /* Replaces DBG::hashSequences (src/graph-builder.cpp:34-126) followed by DBG::processBuffers for
  * every map (:128-223) on one read batch: ASCII -> 2-bit, canonical key, edge byte, insert/RMW of
  * cov + 8 edge counters.  The key % mapCount disk partition of the reference has no counterpart
- * here (single table in HBM). */
+ * here (single table in HBM).  The host variant returns when the batch has been consumed; like the _dev variant it
+ * may leave records pending (KQ_OPT_PENDING_BYTES): kq_sync() applies them and reports table-full conditions. */
 int  kq_count_batch(kq_handle* h, const char* bases, uint64_t len);
 int  kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len);
 

@@ -12,7 +12,7 @@ ENTRY_DTYPE = np.dtype([("key", "<u8"), ("fw", "<u4", 4), ("bw", "<u4", 4), ("co
 DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw", "u1"), ("pad", "u1", 3)])
 
 # every symbol include/kreeq_amd.h declares
-SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_get_profile", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_get_info", "kq_last_error",
+SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_get_profile", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_flush", "kq_get_info", "kq_last_error",
            "kq_abi_version", "kq_device_available", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
            "kq_emit_partitioned_dev", "kq_emit_packed_dev", "kq_insert_packed_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
            "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_merge", "kq_import", "kq_export"]
@@ -31,7 +31,7 @@ class Stats(C.Structure):
 
 class Info(C.Structure):
     _fields_ = [("kmers_counted", C.c_uint64), ("slots_used", C.c_uint64), ("slots_total", C.c_uint64), ("hc_used", C.c_uint64),
-                ("hc_total", C.c_uint64), ("table_bytes", C.c_uint64)]
+                ("hc_total", C.c_uint64), ("table_bytes", C.c_uint64), ("table_passes", C.c_uint64)]
 
 
 _lib = None
@@ -85,6 +85,7 @@ def load():
     L.kq_get_stream.argtypes = [vp]
     L.kq_get_stream.restype = vp
     L.kq_sync.argtypes = [vp]
+    L.kq_flush.argtypes = [vp]
     L.kq_get_info.argtypes = [vp, C.POINTER(Info)]
     L.kq_last_error.restype = C.c_char_p
     L.kq_count_batch.argtypes = [vp, vp, u64]
@@ -145,9 +146,13 @@ class KreeqDB:
     def sync(self):
         _check(load().kq_sync(self._h))
 
+    def flush(self):
+        """apply pending record sets now (asynchronous)"""
+        _check(load().kq_flush(self._h))
+
     def set_option(self, option, value):
         """option: 'trust_capacity' | 'count_path' ('auto'|'direct'|'partitioned') | 'slice_kmers' | 'count_map_range' ((lo, hi))"""
-        opt = {"trust_capacity": 1, "count_path": 2, "slice_kmers": 3, "count_map_range": 4, "profile": 5, "lookup_path": 6, "merge_path": 7, "narrow_mid": 8}[option]
+        opt = {"trust_capacity": 1, "count_path": 2, "slice_kmers": 3, "count_map_range": 4, "profile": 5, "lookup_path": 6, "merge_path": 7, "narrow_mid": 8, "pending_bytes": 9, "test_fail_plan": 100}[option]
         if option == "count_map_range":
             value = int(value[0]) | (int(value[1]) << 16)
         if option in ("count_path", "lookup_path", "merge_path"):

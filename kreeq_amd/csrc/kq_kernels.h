@@ -226,17 +226,31 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
 
 // ---- one generic level of the record split (LevelCfg) -----------------------------------------
 // work units: segment b is cut into ceil(size_b / P2_UNIT) units; unit_base = exclusive prefix
+// (one workgroup; n_seg <= SEG_MAX: every thread takes a run of consecutive segments, the run totals are scanned)
 __global__ __launch_bounds__(1024) void k_lv_units(const unsigned long long* __restrict__ seg_off, LevelCfg lv,
                                                    unsigned long long* __restrict__ unit_base) {
-    __shared__ unsigned long long s_n[NB_MAX];
-    for (uint32_t b = threadIdx.x; b < lv.n_seg; b += blockDim.x)
-        s_n[b] = (seg_off[b + 1] - seg_off[b] + P2_UNIT - 1) / P2_UNIT;
+    __shared__ unsigned long long s_part[1024];
+    const uint32_t tid = threadIdx.x, per = (lv.n_seg + 1023) / 1024;
+    const uint32_t lo = min(tid * per, lv.n_seg), hi = min(lo + per, lv.n_seg);
+    unsigned long long sum = 0;
+    for (uint32_t b = lo; b < hi; ++b) sum += (seg_off[b + 1] - seg_off[b] + P2_UNIT - 1) / P2_UNIT;
+    s_part[tid] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (uint32_t b = 0; b < lv.n_seg; ++b) { unit_base[b] = run; run += s_n[b]; }
-        unit_base[lv.n_seg] = run;
+    if (tid < 64) {                              // wave 0 scans the 1024 partials, 16 per lane
+        unsigned long long loc[16], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { loc[j] = s_part[tid * 16 + j]; tot += loc[j]; }
+        unsigned long long incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { unsigned long long nn = __shfl_up(incl, o, 64); if ((int)tid >= o) incl += nn; }
+        unsigned long long run = incl - tot;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s_part[tid * 16 + j] = run; run += loc[j]; }
+        if (tid == 63) unit_base[lv.n_seg] = incl;
     }
+    __syncthreads();
+    unsigned long long run = s_part[tid];
+    for (uint32_t b = lo; b < hi; ++b) { unit_base[b] = run; run += (seg_off[b + 1] - seg_off[b] + P2_UNIT - 1) / P2_UNIT; }
 }
 __device__ __forceinline__ uint32_t seg_of_unit(const unsigned long long* unit_base, uint32_t n_seg, uint64_t u) {
     uint32_t lo = 0, hi = n_seg;                  // largest b with unit_base[b] <= u (skips empty segments)
@@ -466,14 +480,21 @@ constexpr int P3_THREADS = KQ_P3_THREADS;        // three 48 KiB images per CU (
 // Two instantiations share the regions: HOT = false takes the ordinary ones (deep record prefetch, no
 // folding state: fits the 80 VGPRs that let three workgroups share a CU) and appends the skewed ones
 // to hot_list; HOT = true then walks that list with the folding loop.
+// The records come as up to P3_MAX_SETS record SETS, each sorted by region with its own offset array: the host
+// keeps the sets of several slices / batches pending and applies them in ONE pass over the table (a pass streams
+// every region image in and out, so its cost is shared by all records of all sets; kreeq_amd.hip "pending sets").
 template <int FMT, bool HOT>
-__global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regions(TableView t, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux,
-                                                              int aux_fmt, const unsigned long long* __restrict__ region_base, int table_is_empty,
+__global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regions(TableView t, const P3Set* __restrict__ sets, uint32_t n_sets,
+                                                              int aux_fmt, int table_is_empty,
                                                               unsigned long long* __restrict__ hot_list /*[0] = count, then region ids*/,
                                                               uint32_t narrow_rps /*FMT_NARROW: regions per top-bit bucket*/) {
     constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
-    const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
+    constexpr int PF = KQ_P3_PF;
+    constexpr uint64_t GRP = 64ull * PF;     // records per ticket
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
+    // this region's share of every set: first record, record count, first ticket (groups of GRP records, set after set)
+    __shared__ unsigned long long s_set_lo[P3_MAX_SETS];
+    __shared__ uint32_t s_set_cnt[P3_MAX_SETS], s_set_grp[P3_MAX_SETS + 1];
     __shared__ uint64_t s_lut[64];            // edge indices -> u8x8 increment: one LDS read instead of ~8 VALU per record (-2.4 %)
     if (threadIdx.x < 64) s_lut[threadIdx.x] = idx6_to_pack(threadIdx.x);     // visible after the first region's barrier
     __shared__ unsigned long long s_new, s_kmers;
@@ -490,9 +511,10 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
 #endif
     for (uint64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
         const uint64_t r = HOT ? hot_list[1 + w] : w;
-        const uint64_t lo = region_base[r], hi = region_base[r + 1];
+        uint64_t n_recs = 0;                                            // block-uniform (scalar loads)
+        for (uint32_t q = 0; q < n_sets; ++q) n_recs += sets[q].base[r + 1] - sets[q].base[r];
         const uint32_t narrow_bucket = (NARROW || TOP8) ? (uint32_t)r / narrow_rps : 0u;
-        if (lo == hi) {                                                 // block-uniform
+        if (n_recs == 0) {                                              // block-uniform
             if (!HOT && table_is_empty == 2) {    // lazy kq_clear: this launch initialises every region, also the ones without records
                 ulonglong2* g2 = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
                 for (int i = tid; i < (int)REGION_SLOTS; i += P3_THREADS) g2[i] = make_ulonglong2(0ull, 0ull);
@@ -501,7 +523,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
         }
         // folding costs a ballot + shuffle per iteration: only regions that receive far more records than
         // they have slots (skew, or very deep coverage) take that path, in the second launch
-        if (!HOT && hi - lo > 32ull * REGION_SLOTS) {
+        if (!HOT && n_recs > 32ull * REGION_SLOTS) {
             if (tid == 0) hot_list[1 + atomicAdd(&hot_list[0], 1ull)] = r;
             continue;
         }
@@ -521,6 +543,15 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) img_load(s_img, tid + j * P3_THREADS, v[j].x, v[j].y);
         }
         if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = P3_THREADS / 64; }
+        if (tid < 64) {                                                 // wave 0: ticket ranges of the sets (n_sets <= 64 lanes)
+            uint64_t lo_q = 0; uint32_t cnt_q = 0;
+            if (tid < (int)n_sets) { lo_q = sets[tid].base[r]; cnt_q = (uint32_t)(sets[tid].base[r + 1] - lo_q); }     // a region holds < 2^32 records of one set
+            uint32_t incl = (cnt_q + (uint32_t)GRP - 1) / (uint32_t)GRP;
+#pragma unroll
+            for (int o = 1; o < P3_MAX_SETS; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (tid >= o) incl += v; }
+            if (tid < (int)n_sets) { s_set_lo[tid] = lo_q; s_set_cnt[tid] = cnt_q; s_set_grp[tid + 1] = incl; }
+            if (tid == 0) s_set_grp[0] = 0;
+        }
         __syncthreads();
         KQ_STAMP(0);                                                    // region_base load + image init/load + barrier
         uint32_t n_new = 0, n_ok = 0;
@@ -617,22 +648,34 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
         // walked, so the only wait sits at the top of an iteration on loads that had a whole group's walk
         // to land.  (A conditional load per record made the compiler wait vmcnt(0) right after issuing
         // the next prefetch: a full HBM latency per record, ~4k cycles.)
-        constexpr int PF = KQ_P3_PF;
         uint64_t nxt_rec[PF];
         uint32_t nxt_aux[PF];
-        const uint64_t last = hi - 1;                                  // hi > lo here
         // groups of PF*64 records are handed to waves from an LDS ticket: waves that hit long probe
-        // chains or contended slots take fewer groups, so all waves reach the barrier together
-        constexpr uint64_t GRP = 64ull * PF;
+        // chains or contended slots take fewer groups, so all waves reach the barrier together.
+        // Ticket g lies in set q with s_set_grp[q] <= g < s_set_grp[q + 1] (wave-uniform search over a few sets).
         const uint32_t lane = tid & 63;
-        uint32_t g_cur = tid >> 6;
+        const uint32_t n_grp = s_set_grp[n_sets];
+        uint32_t cur_n = 0;                                            // records in the group whose loads are in flight
+        auto fetch = [&](uint32_t g, uint32_t& n) {                     // issues the loads of ticket g (or of a valid dummy when g is past the end)
+            uint32_t q = 0;
+            if (g < n_grp) { while (g >= s_set_grp[q + 1]) ++q; }
+            else { while (s_set_cnt[q] == 0) ++q; g = s_set_grp[q]; }  // n_recs > 0: some set is not empty
+            q = __builtin_amdgcn_readfirstlane(q);
+            const uint32_t off = (g - s_set_grp[q]) * (uint32_t)GRP, cnt = s_set_cnt[q];
+            const uint64_t lo_q = s_set_lo[q];
+            const uint64_t* rp = sets[q].recs;
+            const uint8_t* ap = sets[q].aux;
+            n = min(cnt - off, (uint32_t)GRP);
 #pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const uint64_t j = min(lo + g_cur * GRP + (uint64_t)q * 64 + lane, last);
-            nxt_rec[q] = NARROW ? (uint64_t)recs32[j] : recs[j];
-            nxt_aux[q] = HAS_AUX ? recs_aux[j] : 0u;
-        }
-        while (lo + g_cur * GRP < hi) {                                 // wave-uniform
+            for (int qq = 0; qq < PF; ++qq) {
+                const uint64_t j = lo_q + min(off + (uint32_t)qq * 64u + lane, cnt - 1u);      // unconditional, index clamped
+                nxt_rec[qq] = NARROW ? (uint64_t)reinterpret_cast<const uint32_t*>(rp)[j] : rp[j];
+                nxt_aux[qq] = HAS_AUX ? ap[j] : 0u;
+            }
+        };
+        uint32_t g_cur = tid >> 6;
+        fetch(g_cur, cur_n);
+        while (g_cur < n_grp) {                                         // wave-uniform
           uint64_t cur_rec[PF];
           uint32_t cur_aux[PF];
 #pragma unroll
@@ -640,18 +683,12 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
           uint32_t g_nxt = 0;
           if (lane == 0) g_nxt = atomicAdd(&s_grp, 1u);
           g_nxt = __builtin_amdgcn_readfirstlane(g_nxt);
-#pragma unroll
-          for (int q = 0; q < PF; ++q) {
-            const uint64_t j = min(lo + g_nxt * GRP + (uint64_t)q * 64 + lane, last);
-            nxt_rec[q] = NARROW ? (uint64_t)recs32[j] : recs[j];
-            nxt_aux[q] = HAS_AUX ? recs_aux[j] : 0u;
-          }
-          const uint64_t base = lo + g_cur * GRP;
+          const uint32_t n_cur = cur_n;
+          fetch(g_nxt, cur_n);
           g_cur = g_nxt;
 #pragma unroll
           for (int q = 0; q < PF; ++q) {
-            const uint64_t i = base + (uint64_t)q * 64 + lane;
-            bool active = i < hi;
+            bool active = (uint32_t)q * 64u + lane < n_cur;
             const uint64_t rec = cur_rec[q];
             const uint32_t aux = cur_aux[q];
             uint64_t pack = 0;

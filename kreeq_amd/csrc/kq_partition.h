@@ -23,6 +23,8 @@ constexpr int MS_THREADS = 256;
 constexpr int MS_ITEMS = 16;
 constexpr int MS_TILE = MS_THREADS * MS_ITEMS;   // 4096 records per multisplit round
 constexpr int NB_MAX = 2048;                     // bins of one split incl. the discard bin: fan-out <= NB_MAX - 1
+constexpr int SEG_MAX = 65536;                   // segments of one split level (256 hash-prefix buckets x up to 256 sub-buckets)
+constexpr uint32_t SUB_BITS_MAX = 8;
 constexpr int REC_EDGE_SHIFT = 56;
 constexpr int PART_MAX_K = 28;                   // packed 8-byte records up to here, WIDE above
 constexpr int AUX_IDX6 = 0, AUX_EDGE_BYTE = 1;
@@ -42,6 +44,11 @@ struct PartCfg {
                           // and the scatter pass give a k-mer the same lane, hence the same sub-bin
     uint32_t sub_bits;    // narrow: > 0 = a middle level cuts each bucket into 2^sub_bits sub-buckets first (very large tables)
 };
+
+// One record set of k_count_regions: records sorted by table region (format FMT_*; `aux` = lockstep u8 array or null)
+// and base[0..n_regions] = first record of every region.
+constexpr int P3_MAX_SETS = 64;
+struct P3Set { const uint64_t* recs; const uint8_t* aux; const unsigned long long* base; uint64_t n_max; };
 
 // One level of the record split.  Input records are grouped in n_seg segments (seg_off[0..n_seg]);
 // a record of segment b with table region r goes to bin (r >> out_shift) - (b << (seg_shift - out_shift)).

@@ -56,6 +56,7 @@ struct kq_handle {
     void* stage = nullptr; size_t stage_bytes = 0;     // device staging for host-buffer entry points
     uint64_t kmers_bound = 0;        // upper bound of instances inserted (sizing the side table)
     uint64_t used_bound = 0;         // upper bound of occupied slots (skips the state read-back)
+    uint64_t hc_check_at = 0;        // instance count from which the side table's fill is looked at again (reserve)
     bool table_empty = true;         // nothing inserted since kq_create / kq_clear
     uint32_t mid_rps = 2048;         // KQ_OPT_NARROW_MID: regions per hash-prefix bucket from which the split gets a middle level
     int merge_path = 0;              // KQ_OPT_MERGE_PATH (of the destination handle): 0 auto, 1 per-entry atomics, 2 region by region
@@ -69,6 +70,16 @@ struct kq_handle {
     bool profile = false;                // KQ_OPT_PROFILE: HIP events around the stages of the partitioned count
     std::vector<std::pair<const char*, hipEvent_t>> marks;
     void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
+    // pending record sets (see "pending sets" below): region-sorted records of earlier slices / batches that have not
+    // been applied to the table yet; one k_count_regions pass takes them all
+    void* arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
+    P3Set* d_sets = nullptr;             // device array [P3_MAX_SETS]
+    int n_pend = 0, pend_fmt = -1, pend_aux_fmt = 0;
+    uint64_t pend_records = 0;           // upper bound of the records in the pending sets
+    int64_t pend_budget = -1;            // KQ_OPT_PENDING_BYTES: -1 auto, 0 = apply every slice at once
+    uint64_t table_passes = 0;           // k_count_regions passes so far
+    bool test_fail_plan = false;         // KQ_OPT_TEST_FAIL_PLAN: the next partition plan fails with KQ_ERR_NOMEM (failure-path tests)
+    void* hot = nullptr; size_t hot_bytes = 0;         // k_count_regions' list of skewed regions
 
     TableView view() const {
         TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; v.k = (uint32_t)k;
@@ -79,6 +90,7 @@ struct kq_handle {
 };
 
 static void marks_reset(kq_handle* h);
+static int flush_pending(kq_handle* h);
 
 // grid-stride kernels: at most `per_cu` workgroups per CU.  8 = what is resident (kernels that flush per-workgroup
 // state at the end); the tile scanners take 32: the dispatcher balances the surplus (-4 % on k_lookup / k_count_direct)
@@ -128,10 +140,15 @@ static int alloc_hc(kq_handle* h, uint64_t cap, HcSlot** out) {
     return KQ_OK;
 }
 
-static int read_state(kq_handle* h) {
+static int read_state_raw(kq_handle* h) {
     HIPC(hipMemcpyAsync(h->st_host, h->st, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
     return KQ_OK;
+}
+static int read_state(kq_handle* h) {
+    int frc = flush_pending(h);          // the device state speaks for everything counted so far
+    if (frc) return frc;
+    return read_state_raw(h);
 }
 static int check_errors(kq_handle* h) {
     int rc = read_state(h);
@@ -146,6 +163,8 @@ static int check_errors(kq_handle* h) {
 // grow (rehash) so that `extra` more distinct k-mers fit at load <= 0.85, and the side table can
 // take every k-mer that may reach cov >= 255 after `extra_instances` more instances.
 static int grow_main(kq_handle* h, uint64_t need_slots) {
+    int frc = flush_pending(h);          // pending records are sorted by the regions of the current geometry
+    if (frc) return frc;
     uint64_t want = h->n_slots();
     while (want < need_slots) want *= 2;
     const uint64_t new_regions = want >> REGION_SHIFT;
@@ -177,6 +196,7 @@ static int grow_hc(kq_handle* h, uint64_t need) {
     return KQ_OK;
 }
 
+constexpr uint64_t HC_CAP_BIG = 1ull << 25;      // side-table floor of jobs beyond 2^31 instances (2.7 GB)
 // Make room for a batch that may add `extra` distinct k-mers and `extra_instances` instances.
 //  main table : load <= 0.85 even if every k-mer of the batch is new (unless the caller vouched for
 //               capacity_hint with KQ_OPT_TRUST_CAPACITY); host-side upper bounds avoid a device round trip.
@@ -197,11 +217,18 @@ static int reserve(kq_handle* h, uint64_t extra, uint64_t extra_instances) {
     }
     h->used_bound += extra;
     h->kmers_bound += extra_instances;
+    // side table: provable sizing (one entry per 255 instances, load <= 0.5) up to 2^23 entries; beyond that it
+    // follows the observed fill with room for an eightfold growth of the high-copy set (as coverage doubles, the copy
+    // number that reaches cov 255 halves): looked at once per doubling of the instance count here, and before every
+    // table pass over pending records (flush_pending).  A side table that fills up anyway is reported as
+    // KQ_ERR_TABLE_FULL by the next synchronising call
     const uint64_t bound = h->kmers_bound / 255 + 1;
     uint64_t need_hc = 2 * std::min<uint64_t>(bound, 1ull << 23);
-    if (bound > (1ull << 23)) {
-        if (!state_read) { rc = read_state(h); if (rc) return rc; }
-        need_hc = std::max<uint64_t>(need_hc, 4 * h->st_host->hc_used);
+    if (bound > (1ull << 23)) need_hc = HC_CAP_BIG;
+    if (bound > (1ull << 23) && h->kmers_bound >= h->hc_check_at && h->n_pend == 0) {
+        if (!state_read) { rc = read_state_raw(h); if (rc) return rc; }
+        need_hc = std::max<uint64_t>(need_hc, 8 * h->st_host->hc_used);
+        h->hc_check_at = 2 * h->kmers_bound;
     }
     if (need_hc > h->hc_cap) { rc = grow_hc(h, need_hc); if (rc) return rc; }
     return KQ_OK;
@@ -291,7 +318,12 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
         // FMT_NARROW / FMT_TOP8 records: 256 hash-prefix buckets of whole regions; k >= HI_K needs it for every table
         // (a slot drops the top 8 hash bits, which its region then implies)
         if (regions >= (uint64_t)NB_MAX || k >= HI_K) regions = (regions + 255) / 256 * 256;
-        if (regions >= (1ull << 19)) regions = (regions + 2047) / 2048 * 2048;         // ... of 8 sub-buckets of whole regions each
+        if (regions >= (1ull << 19)) {                                                  // ... of 2^s sub-buckets of whole regions each, <= 256 regions per sub-bucket
+            uint32_t sbits = 3;
+            while (sbits < SUB_BITS_MAX && (((regions + 255) / 256) >> sbits) > 256) ++sbits;
+            const uint64_t unit = 256ull << sbits;
+            regions = (regions + unit - 1) / unit * unit;
+        }
         rc = alloc_main(h, regions, &h->slots); if (rc) break;
         h->n_regions = regions;
         uint64_t hc = 1u << 16;
@@ -315,6 +347,9 @@ void kq_destroy(kq_handle* h) {
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->stage) (void)hipFree(h->stage);
     if (h->part) (void)hipFree(h->part);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->d_sets) (void)hipFree(h->d_sets);
+    if (h->hot) (void)hipFree(h->hot);
     marks_reset(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -328,7 +363,9 @@ int kq_clear(kq_handle* h) {
     HIPC(hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream));
     h->kmers_bound = 0;
     h->used_bound = 0;
+    h->hc_check_at = 0;
     h->table_empty = true;
+    h->n_pend = 0; h->arena_used = 0; h->pend_records = 0;      // records not applied yet are dropped with the rest
     return KQ_OK;
 }
 
@@ -360,6 +397,14 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_LOOKUP_PATH must be 0, 1 or 2");
             h->lookup_path = (int)value; return KQ_OK;
         case KQ_OPT_PROFILE: h->profile = value != 0; if (!h->profile) marks_reset(h); return KQ_OK;
+        case KQ_OPT_TEST_FAIL_PLAN: h->test_fail_plan = value != 0; return KQ_OK;
+        case KQ_OPT_PENDING_BYTES: {
+            if (value < -1) return fail(KQ_ERR_INVALID, "KQ_OPT_PENDING_BYTES must be -1 (auto), 0 (off) or a byte count");
+            int rc = flush_pending(h);
+            if (rc) return rc;
+            if (h->arena && value != h->pend_budget) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
+            h->pend_budget = value; return KQ_OK;
+        }
         case KQ_OPT_SLICE_KMERS:
             if (value < 1) return fail(KQ_ERR_INVALID, "KQ_OPT_SLICE_KMERS must be positive");
             h->slice_kmers = (uint64_t)value; h->slice_user = true; return KQ_OK;
@@ -389,6 +434,11 @@ int kq_sync(kq_handle* h) {
     HIPC(hipStreamSynchronize(h->stream));
     return check_errors(h);
 }
+int kq_flush(kq_handle* h) {
+    if (!h) return fail(KQ_ERR_INVALID, "null handle");
+    HIPC(hipSetDevice(h->device));
+    return flush_pending(h);
+}
 int kq_get_info(kq_handle* h, kq_info* out) {
     if (!h || !out) return fail(KQ_ERR_INVALID, "null argument");
     HIPC(hipSetDevice(h->device));
@@ -400,6 +450,7 @@ int kq_get_info(kq_handle* h, kq_info* out) {
     out->hc_used = h->st_host->hc_used;
     out->hc_total = h->hc_cap;
     out->table_bytes = h->n_slots() * sizeof(Slot) + h->hc_cap * sizeof(HcSlot);
+    out->table_passes = h->table_passes;
     return KQ_OK;
 }
 
@@ -439,15 +490,20 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false
     if (allow_narrow && (h->k <= (int)NARROW_MAX_K || h->k > PART_MAX_K) && cfg->n_regions >= (uint64_t)NB_MAX && cfg->n_regions % (1u << NARROW_CBITS) == 0) {
         const uint64_t rps = cfg->n_regions >> NARROW_CBITS;
         // one level bucket -> regions while a bucket has < mid_rps regions (the multisplit writes runs of 4096 / fan-out
-        // records), else a middle level of up to 8 sub-buckets: covers every table that fits the HBM (rps < 16384)
+        // records, so the last fan-out should stay near 256), else a middle level of 2^sb sub-buckets (sb <= 8): covers
+        // every table that fits the HBM.  kq_create rounds the region count so that sb reaches its target
         uint32_t sb = 0;
-        if (rps >= h->mid_rps) { sb = 3; while (sb > 0 && rps % (1u << sb)) --sb; }
+        if (rps >= h->mid_rps) {
+            const uint64_t target_nb = std::max<uint64_t>(1, std::min<uint64_t>(256, h->mid_rps / 8));
+            while ((rps >> sb) > target_nb && sb < SUB_BITS_MAX && rps % (2ull << sb) == 0) ++sb;
+        }
         if ((rps >> sb) < (uint64_t)NB_MAX && (sb > 0 || rps < (uint64_t)NB_MAX)) { cfg->narrow = 1; cfg->sub_bits = sb; }
     }
     if (cfg->narrow) { cfg->n_coarse = 1u << NARROW_CBITS; if (cfg->g_shift == 0) cfg->g_shift = 1; }
 }
 // carve the scratch buffer for a batch of at most n_max records; n_tiles = 0 when the input is records
 static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins, bool allow_narrow = false) {
+    if (h->test_fail_plan) { h->test_fail_plan = false; return fail(KQ_ERR_NOMEM, "partition scratch allocation failed (injected by KQ_OPT_TEST_FAIL_PLAN)"); }
     if (n_max >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "a partition pass handles fewer than 2^32 records (got %llu): slice the input", (unsigned long long)n_max);
     plan_cfg(h, &p->cfg, allow_narrow);
     n_max = (n_max + 7) & ~7ull;                                // every record array starts 16-byte aligned and has slack for vector loads
@@ -459,21 +515,23 @@ static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tile
     p->g1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (p1_bins < 512 ? 18 : 12)));
     p->m1_n = (uint64_t)p1_bins * p->g1 * P1_F;
     const uint64_t nb_max = std::max<uint64_t>(std::max<uint64_t>(1ull << p->cfg.g_shift, p->cfg.n_coarse), p->cfg.narrow ? (p->cfg.n_regions >> NARROW_CBITS) >> p->cfg.sub_bits : 0);
-    p->m2_n = (n_max / P2_UNIT + NB_MAX + 2) * nb_max;         // u32 entries, enough for either level
+    const uint64_t seg_max = p->cfg.narrow ? ((uint64_t)1 << NARROW_CBITS) << p->cfg.sub_bits : (uint64_t)NB_MAX;      // segments of the widest level
+    p->m2_n = (n_max / P2_UNIT + seg_max + 2) * nb_max;         // u32 entries, enough for either level
     p->groups_n = std::max<uint64_t>(p->R, (uint64_t)p->cfg.n_coarse << p->cfg.g_shift) + 2;
     p->sums_n = std::max(p->m1_n, p->groups_n) / SCAN_CHUNK + 2;
     const uint64_t aux_words = (n_max + 7) / 8 + 1;
-    const size_t words = (size_t)(2 * n_max + 2 * aux_words + p->m1_n + 2 * (NB_MAX + 2) + p->groups_n + p->sums_n + 4 + (p->R + 2) + (p->m2_n + 1) / 2);
+    const uint64_t rec_words = p->fmt == FMT_NARROW ? n_max / 2 + 2 : n_max;          // narrow records: u32 + lockstep byte
+    const size_t words = (size_t)(2 * rec_words + 2 * aux_words + p->m1_n + 2 * (seg_max + 2) + p->groups_n + p->sums_n + 4 + (p->R + 2) + (p->m2_n + 1) / 2);
     int rc = ensure_buf(&h->part, &h->part_bytes, words * 8);
     if (rc) return rc;
     p->recs1 = (uint64_t*)h->part;
-    p->recs2 = p->recs1 + n_max;
-    p->aux1 = (uint8_t*)(p->recs2 + n_max);
+    p->recs2 = p->recs1 + rec_words;
+    p->aux1 = (uint8_t*)(p->recs2 + rec_words);
     p->aux2 = p->aux1 + aux_words * 8;
     p->m1 = (unsigned long long*)(p->aux2 + aux_words * 8);
     p->seg_off = p->m1 + p->m1_n;
-    p->unit_base = p->seg_off + NB_MAX + 2;
-    p->group_base = p->unit_base + NB_MAX + 2;
+    p->unit_base = p->seg_off + seg_max + 2;
+    p->group_base = p->unit_base + seg_max + 2;
     p->sums = p->group_base + p->groups_n;
     p->total = p->sums + p->sums_n;
     p->hot = p->total + 4;
@@ -535,7 +593,9 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
 }
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
 // afterwards p->group_base[0..n_seg*nb] are the output offsets
-static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint64_t* in, const uint8_t* in_aux, uint64_t* out, uint8_t* out_aux) {
+static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint64_t* in, const uint8_t* in_aux, uint64_t* out, uint8_t* out_aux,
+                      unsigned long long* gb = nullptr /*where the output offsets go (default p->group_base)*/) {
+    if (!gb) gb = p->group_base;
     const int fmt = lv.narrow == 2 ? FMT_TOP8 : lv.narrow ? FMT_NARROW : in_aux != nullptr ? FMT_WIDE : FMT_PACK8;       // input format; lv.top8: packed in, narrow out
     const uint64_t groups = (uint64_t)lv.n_seg * lv.nb;
     hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, lv, p->unit_base);
@@ -546,13 +606,13 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     else if (fmt == FMT_NARROW) hipLaunchKernelGGL(k_lv_hist<FMT_NARROW>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     else if (fmt == FMT_WIDE) hipLaunchKernelGGL(k_lv_hist<FMT_WIDE>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
     else hipLaunchKernelGGL(k_lv_hist<FMT_PACK8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
-    hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, p->group_base);
-    (void)hipMemsetAsync(p->group_base + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
-    scan_u64(h, p->group_base, groups + 1, p->sums, p->total + 1);
+    hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, gb);
+    (void)hipMemsetAsync(gb + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
+    scan_u64(h, gb, groups + 1, p->sums, p->total + 1);
     mark(h, "k_lv_hist+offsets+scan");
     const bool small = lv.nb < 512;
 #define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
-                                        p->seg_off, p->unit_base, p->m2, p->group_base, out, out_aux)
+                                        p->seg_off, p->unit_base, p->m2, gb, out, out_aux)
     if (lv.top8)              { KQ_LVS(FMT_PACK8_TO_NARROW, 512); }
     else if (fmt == FMT_TOP8) { if (small) KQ_LVS(FMT_TOP8, 512); else KQ_LVS(FMT_TOP8, NB_MAX); }
     else if (fmt == FMT_NARROW) { if (small) KQ_LVS(FMT_NARROW, 512); else KQ_LVS(FMT_NARROW, NB_MAX); }
@@ -581,33 +641,109 @@ static LevelCfg level_narrow(const PartCfg& cfg, uint32_t sub_bits = 0, bool mid
 }
 // bucket -> regions for FMT_NARROW records, in one level or (large tables) two; afterwards `*sorted` holds the
 // records grouped by region and p->group_base their offsets
-static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux);
+static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux, const P3Set* dst = nullptr);
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
     return lv;
 }
-static void run_p3(kq_handle* h, PartPlan* p, const uint64_t* sorted, const uint8_t* sorted_aux, int aux_fmt, const unsigned long long* base) {
-    // hot list lives in the (now free) count matrix area: [0] = count, then up to R region ids
-    unsigned long long* hot = p->hot;
-    (void)hipMemsetAsync(hot, 0, 8, h->stream);
-    const dim3 grid((unsigned)std::min<uint64_t>(p->R, 1u << 30)), grid_hot(h->n_cu), block(P3_THREADS);   // one workgroup per region: dispatcher-balanced
+// ---- pending sets ---------------------------------------------------------------------------------
+// A k_count_regions pass streams every region image of the table in and out once, whatever the number of records it
+// applies.  So the region-sorted record set that P1 + the split levels make of a slice is not applied at once: it is
+// kept in an arena (5 bytes per record for the default k) and one pass takes all pending sets together -- when the
+// arena is full, before the table geometry changes, and before anything reads the table or the device state
+// (kq_sync, summary, lookup, export, merge ...).  Counting is commutative, so results do not depend on when a set is
+// applied.  This is what lets a human-scale table (tens of GB) be streamed once per ~10^10 records instead of once
+// per slice; KQ_OPT_PENDING_BYTES bounds the arena (0 = apply every slice at once, the round-1 behaviour).
+__global__ void k_p3set(P3Set* sets, int i, P3Set v) { sets[i] = v; }
+
+static size_t set_bytes(uint64_t n_max, int fmt, uint64_t R) {
+    const size_t rec = fmt == FMT_NARROW ? 4 : 8;
+    const bool aux = fmt == FMT_NARROW || fmt == FMT_WIDE;
+    return ((((size_t)n_max * rec + 63) & ~(size_t)63) + (aux ? (((size_t)n_max + 63) & ~(size_t)63) : 0) + (size_t)(R + 2) * 8 + 255) & ~(size_t)255;
+}
+// room for one more set in the arena (flushes / allocates as needed); false: no deferral for this slice
+static int arena_take(kq_handle* h, uint64_t n_max, int fmt, uint64_t R, P3Set* out, bool* ok) {
+    *ok = false;
+    if (h->pend_budget == 0) return KQ_OK;
+    const size_t need = set_bytes(n_max, fmt, R);
+    if (h->n_pend && (h->n_pend >= P3_MAX_SETS || h->pend_fmt != fmt || h->arena_used + need > h->arena_bytes)) {
+        int rc = flush_pending(h);
+        if (rc) return rc;
+    }
+    if (need > h->arena_bytes) {
+        // (re)size the arena: a few sets, a few times the table, at most half of what is free
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return KQ_OK;
+        size_t budget = h->pend_budget > 0 ? (size_t)h->pend_budget
+                                           : std::min<size_t>((free_b + h->arena_bytes) / 2, std::max<size_t>(4 * need, 4 * (size_t)h->n_slots() * sizeof(Slot)));
+        if (budget < need) return KQ_OK;
+        if (h->arena) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
+        if (hipMalloc(&h->arena, budget) != hipSuccess) { (void)hipGetLastError(); h->arena = nullptr; return KQ_OK; }
+        h->arena_bytes = budget; h->arena_used = 0;
+    }
+    uint8_t* base = (uint8_t*)h->arena + h->arena_used;
+    const size_t rec = fmt == FMT_NARROW ? 4 : 8;
+    const bool aux = fmt == FMT_NARROW || fmt == FMT_WIDE;
+    out->recs = (const uint64_t*)base;
+    base += ((size_t)n_max * rec + 63) & ~(size_t)63;
+    out->aux = aux ? base : nullptr;
+    if (aux) base += ((size_t)n_max + 63) & ~(size_t)63;
+    out->base = (const unsigned long long*)base;
+    out->n_max = n_max;
+    h->arena_used += need;
+    *ok = true;
+    return KQ_OK;
+}
+// make `set` (records of format fmt, sorted by region of the CURRENT geometry) part of the next table pass
+static int pend_add(kq_handle* h, const P3Set& set, int fmt, int aux_fmt) {
+    if (h->n_pend && (h->n_pend >= P3_MAX_SETS || h->pend_fmt != fmt || h->pend_aux_fmt != aux_fmt)) {
+        int rc = flush_pending(h);
+        if (rc) return rc;
+    }
+    if (!h->d_sets) HIPC(hipMalloc((void**)&h->d_sets, sizeof(P3Set) * P3_MAX_SETS));
+    hipLaunchKernelGGL(k_p3set, dim3(1), dim3(1), 0, h->stream, h->d_sets, h->n_pend, set);
+    h->pend_fmt = fmt; h->pend_aux_fmt = aux_fmt;
+    ++h->n_pend;
+    h->pend_records += set.n_max;
+    return KQ_OK;
+}
+// P3 over all pending sets
+static int flush_pending(kq_handle* h) {
+    if (!h->n_pend) return KQ_OK;
+    const uint64_t R = h->n_regions;
+    int rc = ensure_buf(&h->hot, &h->hot_bytes, (size_t)(R + 2) * 8);
+    if (rc) return rc;
+    if (h->kmers_bound / 255 + 1 > (1ull << 23)) {       // large jobs: the side table follows its observed fill (see reserve)
+        rc = read_state_raw(h); if (rc) return rc;
+        const uint64_t need_hc = std::max<uint64_t>(HC_CAP_BIG, 8 * h->st_host->hc_used);
+        if (need_hc > h->hc_cap) { rc = grow_hc(h, need_hc); if (rc) return rc; }
+    }
+    unsigned long long* hot = (unsigned long long*)h->hot;       // [0] = count, then up to R region ids
+    HIPC(hipMemsetAsync(hot, 0, 8, h->stream));
+    const dim3 grid((unsigned)std::min<uint64_t>(R, 1u << 30)), grid_hot(h->n_cu), block(P3_THREADS);   // one workgroup per region: dispatcher-balanced
     // 1: the slot array holds the empty image (skip reading it); 2: logically empty but not initialised (lazy kq_clear):
     // also write the image of regions without records.  A dirty array is never read, whatever table_empty says
     const int empty = h->slots_dirty ? 2 : h->table_empty ? 1 : 0;
-    const uint32_t rps = (p->fmt == FMT_NARROW || p->fmt == FMT_TOP8) ? (uint32_t)(p->R >> NARROW_CBITS) : 1u;
+    const int fmt = h->pend_fmt;
+    const uint32_t rps = (fmt == FMT_NARROW || fmt == FMT_TOP8) ? (uint32_t)(R >> NARROW_CBITS) : 1u;
 #define KQ_P3(F) do { \
-        hipLaunchKernelGGL((k_count_regions<F, false>), grid, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot, rps); \
-        hipLaunchKernelGGL((k_count_regions<F, true>), grid_hot, block, 0, h->stream, h->view(), sorted, sorted_aux, aux_fmt, base, empty, hot, rps); } while (0)
-    if (p->fmt == FMT_NARROW) KQ_P3(FMT_NARROW);
-    else if (p->fmt == FMT_TOP8) KQ_P3(FMT_TOP8);
-    else if (sorted_aux) KQ_P3(FMT_WIDE);
+        hipLaunchKernelGGL((k_count_regions<F, false>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, h->pend_aux_fmt, empty, hot, rps); \
+        hipLaunchKernelGGL((k_count_regions<F, true>), grid_hot, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, h->pend_aux_fmt, empty, hot, rps); } while (0)
+    if (fmt == FMT_NARROW) KQ_P3(FMT_NARROW);
+    else if (fmt == FMT_TOP8) KQ_P3(FMT_TOP8);
+    else if (fmt == FMT_WIDE) KQ_P3(FMT_WIDE);
     else KQ_P3(FMT_PACK8);
 #undef KQ_P3
+    h->n_pend = 0; h->arena_used = 0; h->pend_records = 0;
+    ++h->table_passes;
     // only now (every failure path of the partition stages lies before this point): the table has content, and a lazily
     // cleared slot array has been written in full
     h->slots_dirty = false;
     h->table_empty = false;
+    mark(h, "k_count_regions");
+    HIPC(hipGetLastError());
+    return KQ_OK;
 }
 
 // can the record split reach every region of this table?  (5-byte records: up to 256 x 8 x 2047 regions, i.e.
@@ -618,23 +754,33 @@ static bool part_table_ok(const kq_handle* h, bool narrow_possible) {
     PartCfg c; plan_cfg(h, &c, true);
     return c.narrow != 0;
 }
-static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux) {
+// `dst` != nullptr: the last level writes records, lockstep bytes and region offsets there (a pending set in the arena)
+static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux, const P3Set* dst) {
     const uint32_t sb = p->cfg.sub_bits;
     const bool t8 = p->fmt == FMT_TOP8;
     uint8_t* a1 = t8 ? nullptr : p->aux1;
     uint8_t* a2 = t8 ? nullptr : p->aux2;
+    uint64_t* fin = dst ? const_cast<uint64_t*>(dst->recs) : (sb == 0 ? p->recs2 : p->recs1);
+    uint8_t* fin_aux = t8 ? nullptr : dst ? const_cast<uint8_t*>(dst->aux) : (sb == 0 ? a2 : a1);
+    unsigned long long* fin_base = dst ? const_cast<unsigned long long*>(dst->base) : p->group_base;
     if (sb == 0) {
-        run_level(h, p, level_narrow(p->cfg, 0, false, t8), p->recs1, a1, p->recs2, a2);
-        *sorted = p->recs2; *sorted_aux = a2;
-        return;
+        run_level(h, p, level_narrow(p->cfg, 0, false, t8), p->recs1, a1, fin, fin_aux, fin_base);
+    } else {
+        run_level(h, p, level_narrow(p->cfg, sb, true, t8), p->recs1, a1, p->recs2, a2);
+        (void)hipMemcpyAsync(p->seg_off, p->group_base, (size_t)(((1u << NARROW_CBITS) << sb) + 1) * 8, hipMemcpyDeviceToDevice, h->stream);
+        run_level(h, p, level_narrow(p->cfg, sb, false, t8), p->recs2, a2, fin, fin_aux, fin_base);
     }
-    run_level(h, p, level_narrow(p->cfg, sb, true, t8), p->recs1, a1, p->recs2, a2);
-    (void)hipMemcpyAsync(p->seg_off, p->group_base, (size_t)(((1u << NARROW_CBITS) << sb) + 1) * 8, hipMemcpyDeviceToDevice, h->stream);
-    run_level(h, p, level_narrow(p->cfg, sb, false, t8), p->recs2, a2, p->recs1, a1);
-    *sorted = p->recs1; *sorted_aux = a1;
+    *sorted = fin; *sorted_aux = fin_aux;
 }
 
-// partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> P3 (LDS regions)
+// a set in the scratch buffers is applied at once (the scratch is reused by the next slice)
+static int pend_or_apply(kq_handle* h, const P3Set& set, int fmt, int aux_fmt, bool in_arena) {
+    int rc = pend_add(h, set, fmt, aux_fmt);
+    if (rc) return rc;
+    return in_arena ? KQ_OK : flush_pending(h);
+}
+
+// partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> a pending set for P3 (LDS regions)
 static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er) {
     PartPlan p;
     PartCfg c0; plan_cfg(h, &c0, true);
@@ -647,22 +793,24 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     uint8_t* a1 = has_aux ? p.aux1 : nullptr;
     uint8_t* a2 = has_aux ? p.aux2 : nullptr;
     p.cfg.filt_lo = h->filt_lo; p.cfg.filt_hi = h->filt_hi;      // KQ_OPT_COUNT_MAP_RANGE
+    const bool leveled = p.fmt == FMT_NARROW || p.fmt == FMT_TOP8 || p.two_level;
+    P3Set set; bool in_arena = false;
+    if (leveled) { rc = arena_take(h, p.n_max, p.fmt, p.R, &set, &in_arena); if (rc) return rc; }
     marks_reset(h);
     mark(h, "start");
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
     if (p.fmt == FMT_NARROW || p.fmt == FMT_TOP8) {
         const uint64_t* sorted; const uint8_t* sorted_aux;
-        run_narrow_levels(h, &p, &sorted, &sorted_aux);
-        run_p3(h, &p, sorted, sorted_aux, AUX_IDX6, p.group_base);
+        run_narrow_levels(h, &p, &sorted, &sorted_aux, in_arena ? &set : nullptr);
+        if (!in_arena) set = P3Set{sorted, sorted_aux, p.group_base, p.n_max};
     } else if (p.two_level) {
-        run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
-        run_p3(h, &p, p.recs2, a2, AUX_IDX6, p.group_base);
+        if (in_arena) run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, const_cast<uint64_t*>(set.recs), const_cast<uint8_t*>(set.aux), const_cast<unsigned long long*>(set.base));
+        else { run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2); set = P3Set{p.recs2, a2, p.group_base, p.n_max}; }
     } else {
-        run_p3(h, &p, p.recs1, a1, AUX_IDX6, p.seg_off);       // bins were the regions themselves
+        set = P3Set{p.recs1, a1, p.seg_off, p.n_max};          // bins were the regions themselves
     }
-    mark(h, "k_count_regions");
     HIPC(hipGetLastError());
-    return KQ_OK;
+    return pend_or_apply(h, set, p.fmt, AUX_IDX6, in_arena);
 }
 // partitioned count of n records already on the device (multi-GPU receive side, kq_insert_records_dev).
 // d_aux == nullptr: packed 8-byte records; else WIDE records with d_aux in `aux_fmt`.
@@ -671,19 +819,21 @@ static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const
     PartPlan p;
     int rc = plan_alloc(h, &p, n, 0, 1, /*allow_narrow=*/!d_aux && !raw);
     if (rc) return rc;
+    P3Set set; bool in_arena = false;
     if (p.fmt == FMT_NARROW) {
         // packed records of kq_emit_packed_dev on a narrow-eligible table: the first level splits on the top 8 hash
         // bits and writes 5-byte records, the rest is the narrow path of count_partitioned
+        rc = arena_take(h, p.n_max, p.fmt, p.R, &set, &in_arena); if (rc) return rc;
         hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, h->stream, p.seg_off, 0ull, (unsigned long long)n);
         LevelCfg first = level_flat_to_coarse(p.cfg);
         first.top8 = 1; first.nb = 1u << NARROW_CBITS;
         run_level(h, &p, first, d_recs, nullptr, p.recs1, p.aux1);
         HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)((1u << NARROW_CBITS) + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
         const uint64_t* sorted; const uint8_t* sorted_aux;
-        run_narrow_levels(h, &p, &sorted, &sorted_aux);
-        run_p3(h, &p, sorted, sorted_aux, AUX_IDX6, p.group_base);
+        run_narrow_levels(h, &p, &sorted, &sorted_aux, in_arena ? &set : nullptr);
+        if (!in_arena) set = P3Set{sorted, sorted_aux, p.group_base, p.n_max};
         HIPC(hipGetLastError());
-        return KQ_OK;
+        return pend_or_apply(h, set, FMT_NARROW, AUX_IDX6, in_arena);
     }
     if (d_aux) p.fmt = FMT_WIDE;
     uint8_t* a1 = d_aux ? p.aux1 : nullptr;
@@ -696,12 +846,12 @@ static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const
         // the coarse offsets become the segment table of the next level
         HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)(p.cfg.n_coarse + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
         run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, p.recs2, a2);
-        run_p3(h, &p, p.recs2, a2, aux_fmt, p.group_base);
+        set = P3Set{p.recs2, a2, p.group_base, p.n_max};
     } else {
-        run_p3(h, &p, p.recs1, a1, aux_fmt, p.group_base);
+        set = P3Set{p.recs1, a1, p.group_base, p.n_max};
     }
     HIPC(hipGetLastError());
-    return KQ_OK;
+    return pend_or_apply(h, set, p.fmt, aux_fmt, false);
 }
 
 int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
@@ -712,10 +862,18 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
     // a resident batch of any size is processed in slices of <= 2^28 k-mer starts (the partition
     // scratch is 16 B per start); a slice scans one extra base on the left and k on the right, so
     // k-mers and edges across a cut are seen exactly once
-    // The partitioned path streams the whole table once per slice, so a slice should bring a few records per
-    // slot: with a large table (and memory to spare for 16 B of scratch per start) slices grow up to 2^31 starts
+    // Without pending sets (KQ_OPT_PENDING_BYTES = 0) the partitioned path streams the whole table once per slice, so a
+    // slice should bring a few records per slot: with a large table (and memory to spare for 16 B of scratch per start)
+    // slices grow up to 2^31 starts.  With pending sets the table pass is shared by many slices and the default holds.
     uint64_t slice = h->slice_kmers;
-    if (!h->slice_user && kmers > slice && 2 * h->n_slots() > slice) {
+    if (h->pend_budget != 0 && !h->slice_user && kmers > slice) {
+        // large tables split records over up to 65536 segments before the last level: slices of up to 2^30 starts keep
+        // a few work units per segment (10 B of scratch per start for the default k)
+        slice = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(slice, h->n_slots() / 4));
+        const uint64_t n_slices = (kmers + slice - 1) / slice;
+        slice = (kmers + n_slices - 1) / n_slices;           // equal slices
+    }
+    if (h->pend_budget == 0 && !h->slice_user && kmers > slice && 2 * h->n_slots() > slice) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const uint64_t by_mem = (uint64_t)((free_b + h->part_bytes) / 24);          // 16 B scratch + margin per start
@@ -731,11 +889,18 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
         const EmitRange er{a - sub_off, b - sub_off};
         const uint8_t* ab; uint64_t lead;
         aligned_view(d_bases + sub_off, &ab, &lead);
-        // partitioned path streams the whole table once per slice (2 x 24 B per slot) on top of ~37 B per
-        // record; the atomic path costs ~95 ps per record whatever the table size (~480 B at the
-        // part's streaming rate): partition unless the table is more than ~200 B per record of the slice
+        // a table pass streams the whole table (2 x 16 B per slot) on top of ~37 B per record; the atomic path costs
+        // ~95 ps per record whatever the table size (~480 B at the part's streaming rate): partition unless the table
+        // is more than ~200 B per record the pass will apply -- this slice, plus what is pending already, times the
+        // slices of this size the arena can still take (at most 8: the caller may read the table any time)
+        double pass_records = (double)(b - a);
+        if (h->pend_budget != 0) {
+            const double per_set = (double)set_bytes(b - a, FMT_PACK8, h->n_regions);
+            const double room = h->arena ? (double)h->arena_bytes : 4.0 * (double)h->n_slots() * sizeof(Slot);
+            pass_records = (double)h->pend_records + (double)(b - a) * std::max(1.0, std::min(8.0, room / per_set));
+        }
         bool part = (b - a) >= (1u << 20) && part_table_ok(h, true) &&
-                    (double)h->n_slots() * sizeof(Slot) <= 200.0 * (double)(b - a);
+                    (double)h->n_slots() * sizeof(Slot) <= 200.0 * pass_records;
         if (h->count_path == 1) part = false;
         if (h->count_path == 2) {
             if (!part_table_ok(h, true)) return fail(KQ_ERR_INVALID, "table too large for the partitioned path");
@@ -764,7 +929,10 @@ int kq_count_batch(kq_handle* h, const char* bases, uint64_t len) {
     if (rc) return rc;
     rc = kq_count_batch_dev(h, (const char*)d, len);
     if (rc) return rc;
-    return kq_sync(h);
+    // the staging buffer is free again once the stream has drained; records may stay pending (errors of a pending
+    // pass surface at the next kq_sync / read of the table)
+    HIPC(hipStreamSynchronize(h->stream));
+    return KQ_OK;
 }
 
 static int emit_ordered(kq_handle* h, const char* d_bases, uint64_t len, uint64_t* d_keys, uint8_t* d_edges, uint64_t cap,
@@ -1020,6 +1188,7 @@ int kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uint
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
     const uint32_t map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
+    { int frc = flush_pending(h); if (frc) return frc; }
     materialize(h);
     // counters only, a sequence worth partitioning, and a table small enough next to it (the partitioned path
     // streams the whole table once per slice): regions staged in LDS instead of one random sector per k-mer
@@ -1083,6 +1252,8 @@ int kq_merge(kq_handle* dst, kq_handle* src) {
     if (dst->k != src->k || dst->map_count != src->map_count || dst->device != src->device)
         return fail(KQ_ERR_MISMATCH, "handles differ in k / map_count / device");    // src/input.cpp:136-139
     HIPC(hipSetDevice(dst->device));
+    { int frc = flush_pending(dst); if (frc) return frc; }
+    { int frc = flush_pending(src); if (frc) return frc; }
     materialize(src);                                   // on src's stream, before the sync below
     int rc = kq_sync(src);
     if (rc) return rc;

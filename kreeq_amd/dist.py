@@ -87,6 +87,9 @@ class GpuEngine:
     def sync(self):
         self.db.sync()
 
+    def flush(self):
+        self.db.flush()
+
     def clear(self):
         self.db.clear()
 

@@ -41,3 +41,60 @@ def mutate(codes, rate, seed=3):
     rng = np.random.default_rng(seed)
     e = rng.random(len(codes)) < rate
     return np.where(e, (codes + rng.integers(1, 4, len(codes), dtype=np.uint8)) & 3, codes).astype(np.uint8)
+
+
+# ---- the same shapes generated ON THE GPU (torch RNG, fixed seeds): BASELINE.md configs[2]-[4] never leave HBM ----
+def genome_dev(length, dev, seed=1):
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    return torch.randint(0, 4, (length,), dtype=torch.uint8, device=dev, generator=g)
+
+
+def mutate_dev(codes, rate, seed=3):
+    """-> (mutated codes, number of substitutions)"""
+    import torch
+    g = torch.Generator(device=codes.device)
+    g.manual_seed(seed)
+    n = codes.numel()
+    out = codes.clone()
+    n_sub = 0
+    for lo in range(0, n, 1 << 28):                     # bounded temporaries
+        hi = min(n, lo + (1 << 28))
+        mut = torch.rand(hi - lo, device=codes.device, generator=g) < rate
+        add = torch.randint(1, 4, (hi - lo,), dtype=torch.uint8, device=codes.device, generator=g)
+        out[lo:hi] = torch.where(mut, (codes[lo:hi] + add) & 3, codes[lo:hi])
+        n_sub += int(mut.sum())
+    return out, n_sub
+
+
+def ascii_dev(codes):
+    import torch
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=codes.device)
+    out = torch.empty_like(codes)
+    for lo in range(0, codes.numel(), 1 << 28):
+        hi = min(codes.numel(), lo + (1 << 28))
+        out[lo:hi] = acgt[codes[lo:hi].long()]
+    return out
+
+
+def reads_dev(genome, n_reads, read_len, gen, err=0.005, chunk=1_000_000):
+    """one read batch on the device: uint8 tensor of n_reads*(read_len+1)-1 bytes, reads separated by '\\n';
+    uniform start, strand 50/50, substitutions at `err` per base.  `gen` = torch.Generator on the genome's device
+    (its state advances, so consecutive calls give different reads)."""
+    import torch
+    dev = genome.device
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    ar = torch.arange(read_len, device=dev)
+    out = torch.full((n_reads, read_len + 1), 10, dtype=torch.uint8, device=dev)
+    G = genome.numel()
+    for lo in range(0, n_reads, chunk):
+        n = min(chunk, n_reads - lo)
+        starts = torch.randint(0, G - read_len + 1, (n,), device=dev, generator=gen)
+        codes = genome[starts[:, None] + ar[None, :]]
+        rev = torch.rand(n, device=dev, generator=gen) < 0.5
+        codes = torch.where(rev[:, None], 3 - codes.flip(1), codes)
+        e = torch.rand((n, read_len), device=dev, generator=gen) < err
+        codes = torch.where(e, (codes + torch.randint(1, 4, (n, read_len), dtype=torch.uint8, device=dev, generator=gen)) & 3, codes)
+        out[lo:lo + n, :read_len] = acgt[codes.long()]
+    return out.reshape(-1)[:-1]

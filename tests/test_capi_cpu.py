@@ -25,7 +25,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.kq_abi_version() == 1
+    assert lib.kq_abi_version() == 2
 
 
 def test_no_cpu_fallback(lib):

@@ -1,0 +1,146 @@
+"""Pending record sets of the partitioned count (KQ_OPT_PENDING_BYTES): region-sorted records of several slices /
+batches are applied in one k_count_regions pass.  Whatever the arena size and whenever a pass happens, the table must
+equal the oracle's (counting is commutative)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kq():
+    import kreeq_amd
+    if not kreeq_amd.device_available():
+        pytest.fail("no gfx950 device: the product has no CPU fallback")
+    return kreeq_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+def _batches(n, k, seed, genome=400_000):
+    # the same genome for every batch (different reads): most k-mers recur, some are batch-private errors
+    out = []
+    for i in range(n):
+        b, _ = H.synth_reads(11000 + 500 * i, 150, genome, seed=seed, err=0.004 + 0.002 * i, n_rate=0.001)
+        out.append(b)
+    return out
+
+
+# arena sizes: automatic, off, one set at a time (5 MB < two sets of ~1.5 M records x 5 B + offsets), a few sets
+@pytest.mark.parametrize("k,hint,pending", [(21, 5_000_000, -1), (21, 5_000_000, 0), (21, 5_000_000, 12_000_000), (21, 5_000_000, 26_000_000),
+                                            (21, 0, -1), (27, 4_000_000, -1), (31, 5_000_000, -1), (31, 0, 30_000_000), (13, 3_000_000, -1)])
+def test_pending_sets_vs_oracle(kq, O, k, hint, pending):
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=hint), O.OracleDB(k, 128)
+    gpu.set_option("count_path", "partitioned")
+    gpu.set_option("pending_bytes", pending)
+    if hint:
+        gpu.set_option("trust_capacity", 1)      # otherwise the worst-case reservation of a batch (all k-mers new) reads the state, which applies what is pending
+    for b in _batches(5, k, seed=100 + k):
+        gpu.count_batch(b)                       # no read of the table in between: the sets stay pending
+        cpu.count_batch(b, threads=8)
+    assert gpu.summary() == cpu.summary()
+    passes = gpu.info()["table_passes"]
+    if pending == 0:
+        assert passes == 5                        # one table pass per batch
+    elif pending == -1 and hint:
+        assert passes == 1                        # all five sets in one pass
+    elif pending == 12_000_000:
+        assert passes == 5                        # the arena holds one set: every new set flushes the previous one
+    assert H.entries_equal(gpu.export(), cpu.export())
+    # more batches on top of a filled table, then a region-wise lookup (which must see them)
+    extra = _batches(2, k, seed=7)
+    for b in extra:
+        gpu.count_batch(b)
+        cpu.count_batch(b, threads=8)
+    _, genome = H.synth_reads(10, 150, 400_000, seed=100 + k)
+    gpu.set_option("lookup_path", "partitioned")
+    c_gpu, _ = gpu.lookup_sequence(genome)
+    c_cpu, _ = cpu.validate_sequence(genome)
+    assert np.array_equal(c_gpu, c_cpu)
+    assert H.entries_equal(gpu.export(), cpu.export())
+
+
+def test_pending_mixed_with_other_entry_points(kq, O):
+    """pending sets + direct count + explicit records + import + merge + clear"""
+    k = 21
+    bs = _batches(4, k, seed=31)
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=5_000_000), O.OracleDB(k, 128)
+    gpu.set_option("count_path", "partitioned")
+    gpu.count_batch(bs[0])
+    cpu.count_batch(bs[0], threads=8)
+    gpu.set_option("count_path", "direct")        # global atomics while a set is pending: adds commute
+    gpu.count_batch(bs[1][:200_000])
+    cpu.count_batch(bs[1][:200_000], threads=8)
+    keys, edges = kq.KreeqDB(k, 128).emit_records(bs[2][:100_000])
+    gpu.insert_records(keys, edges)
+    cpu.insert_records(keys, edges)
+    gpu.set_option("count_path", "partitioned")
+    gpu.count_batch(bs[3])
+    cpu.count_batch(bs[3], threads=8)
+    other, oref = kq.KreeqDB(k, 128, capacity_hint=3_000_000), O.OracleDB(k, 128)
+    other.set_option("count_path", "partitioned")
+    other.count_batch(bs[2])                      # stays pending in `other` until the merge reads it
+    oref.count_batch(bs[2], threads=8)
+    gpu.merge(other)
+    cpu.merge(oref)
+    assert gpu.summary() == cpu.summary()
+    assert H.entries_equal(gpu.export(), cpu.export())
+    # clear drops what is pending
+    gpu.count_batch(bs[0])
+    gpu.clear()
+    gpu.count_batch(bs[1])
+    c2 = O.OracleDB(k, 128)
+    c2.count_batch(bs[1], threads=8)
+    assert H.entries_equal(gpu.export(), c2.export())
+
+
+def test_pending_hot_kmers(kq, O):
+    """skewed regions (homopolymer reads) across several pending sets: the second launch folds them"""
+    k = 21
+    rng = np.random.default_rng(5)
+    normal = _batches(3, k, seed=77)
+    hot = b"\n".join([b"A" * 150] * 9000 + [b"ACGT" * 37 + b"AC"] * 3000)
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=5_000_000), O.OracleDB(k, 128)
+    gpu.set_option("count_path", "partitioned")
+    for b in (normal[0], hot, normal[1], hot, normal[2]):
+        gpu.count_batch(b)
+        cpu.count_batch(b, threads=8)
+    assert gpu.summary() == cpu.summary()
+    out = gpu.export()
+    assert H.entries_equal(out, cpu.export())
+    assert out["cov"].max() == 2 * 9000 * 130
+
+
+def test_failed_count_after_clear_leaves_handle_usable(kq, O):
+    """a partitioned count that fails before its table pass (here: an injected scratch-allocation failure)
+    right after a lazy kq_clear must not leave the handle believing that the uninitialised slot array has content"""
+    k = 21
+    bs = _batches(2, k, seed=9)
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=5_000_000), O.OracleDB(k, 128)
+    gpu.set_option("count_path", "partitioned")
+    gpu.count_batch(bs[0])
+    gpu.sync()
+    gpu.clear()                                   # lazy: the slot array still holds batch 0
+    gpu.set_option("test_fail_plan", 1)
+    with pytest.raises(kq.KqError) as e:
+        gpu.count_batch(bs[1])
+    assert e.value.code == -4
+    gpu.count_batch(bs[1])                        # must see an EMPTY table, not the stale image
+    cpu.count_batch(bs[1], threads=8)
+    assert gpu.summary() == cpu.summary()
+    assert H.entries_equal(gpu.export(), cpu.export())
+    # same with the direct path following the failure
+    gpu.clear()
+    gpu.set_option("test_fail_plan", 1)
+    with pytest.raises(kq.KqError):
+        gpu.count_batch(bs[0])
+    gpu.set_option("count_path", "direct")
+    gpu.count_batch(bs[1])
+    assert H.entries_equal(gpu.export(), cpu.export())
