@@ -31,15 +31,17 @@ def hipcc():
     raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU fallback)")
 
 
-def build_lib(force=False, verbose=False):
-    if force or _stale(LIB, HIP_DEPS):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+def build_lib(force=False, verbose=False, out=None, defines=()):
+    """out / defines: a tuning variant of the library (A/B measurements: KQ_LIB=<path> selects it at load time)"""
+    target = out or LIB
+    if force or _stale(target, HIP_DEPS):
+        os.makedirs(os.path.dirname(target), exist_ok=True)
         cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wextra",
-               "-o", LIB] + HIP_SOURCES
+               "-o", target] + ["-D" + d for d in defines] + HIP_SOURCES
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return target
 
 
 def host_sources():

@@ -69,11 +69,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_build.LIB):
-        raise KqError(-2, f"{_build.LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("KQ_LIB") or _build.LIB          # KQ_LIB: a tuning variant built by kreeq_amd.build.build_lib(out=...)
+    if not os.path.exists(path):
+        raise KqError(-2, f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(the product has no CPU fallback)")
     _preload_process_hip_runtime()
-    L = C.CDLL(_build.LIB)
+    L = C.CDLL(path)
     vp, u64, u32, u16, ci = C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint16, C.c_int
     L.kq_create.argtypes = [C.POINTER(vp), ci, ci, ci, u64]
     L.kq_destroy.argtypes = [vp]

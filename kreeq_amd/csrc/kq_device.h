@@ -58,6 +58,7 @@ struct TableView {
     DevState* st;
     uint32_t k;             // k-mer length: the table hash mixes exactly 2k bits
     uint32_t rps;           // k >= HI_K: regions per top-8-bit hash bucket (n_regions / 256, exact); else 0
+    const uint32_t* rstart; // rstart[r] = smallest value of the top 32 hash bits that maps to region r = ceil(r 2^32 / n_regions)
 };
 
 // Table hash = an INVERTIBLE mix of the key: one xorshift-multiply-xorshift round that is a bijection

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
     constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, CONVERT = FMT == FMT_PACK8_TO_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
     constexpr int MS_FMT = CONVERT ? FMT_NARROW : TOP8 ? FMT_PACK8 : FMT;                  // format of the records this kernel writes
     const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
-    __shared__ MsShared<NBC, MS_FMT> s;
+    __shared__ MsShared<NBC, MS_FMT, LV_TILE> s;
     const uint32_t nb = lv.nb;
     const uint64_t n_units = unit_base[lv.n_seg];
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
@@ -471,6 +471,38 @@ extern "C" int kq_debug_stamps(unsigned long long* out, int reset) {
 #else
 #define KQ_STAMP(i) do { } while (0)
 #endif
+// loads through a pointer that was itself loaded from memory are FLAT loads unless the address space is stated, and a
+// flat load counts on lgkmcnt as well as vmcnt: every LDS wait of the record walk would also wait for the prefetch
+template <class T> __device__ __forceinline__ T ld_global(const T* p) { return *(const __attribute__((address_space(1))) T*)p; }
+
+// A wave's view of the pending sets of one region: lane q < n_sets holds set q's share (first record, record count,
+// first ticket); tickets = groups of GRP records, set after set.  Built by every wave for itself (two loads + a wave
+// scan, no LDS, no barrier); a ticket is located with one ballot.
+template <uint32_t GRP>
+struct SetTickets {
+    uint64_t lo; uint32_t cnt, first, n_grp;
+    __device__ __forceinline__ void build(const P3Set* __restrict__ sets, uint32_t n_sets, uint64_t r, uint32_t lane) {
+        lo = 0; cnt = 0;
+        if (lane < n_sets) { const unsigned long long* b = ld_global(&sets[lane].base); lo = ld_global(b + r); cnt = (uint32_t)(ld_global(b + r + 1) - lo); }   // a region holds < 2^32 records of one set
+        const uint32_t mine = (cnt + GRP - 1) / GRP;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < P3_MAX_SETS; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += v; }
+        first = incl - mine;
+        n_grp = __builtin_amdgcn_readlane(incl, 63);
+    }
+    // set of ticket g (any non-empty set when g is past the end: the caller only needs loadable addresses then)
+    __device__ __forceinline__ void locate(uint32_t g, uint32_t& q, uint32_t& off, uint32_t& q_cnt, uint64_t& q_lo) const {
+        const uint64_t nonempty = __ballot(cnt != 0);
+        const uint64_t m = __ballot(cnt != 0 && first <= g);
+        q = (g < n_grp && m) ? 63u - (uint32_t)__clzll((unsigned long long)m) : (uint32_t)__ffsll((unsigned long long)nonempty) - 1u;
+        const uint32_t f = __builtin_amdgcn_readlane(first, q);
+        q_cnt = __builtin_amdgcn_readlane(cnt, q);
+        q_lo = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(lo >> 32), q) << 32) | __builtin_amdgcn_readlane((uint32_t)lo, q);
+        off = (g < n_grp ? g - f : 0u) * GRP;
+    }
+};
+
 #ifndef KQ_P3_THREADS
 #define KQ_P3_THREADS 512
 #define KQ_P3_OCC 6
@@ -492,9 +524,6 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
     constexpr int PF = KQ_P3_PF;
     constexpr uint64_t GRP = 64ull * PF;     // records per ticket
     __shared__ uint64_t s_img[REGION_SLOTS * 3];
-    // this region's share of every set: first record, record count, first ticket (groups of GRP records, set after set)
-    __shared__ unsigned long long s_set_lo[P3_MAX_SETS];
-    __shared__ uint32_t s_set_cnt[P3_MAX_SETS], s_set_grp[P3_MAX_SETS + 1];
     __shared__ uint64_t s_lut[64];            // edge indices -> u8x8 increment: one LDS read instead of ~8 VALU per record (-2.4 %)
     if (threadIdx.x < 64) s_lut[threadIdx.x] = idx6_to_pack(threadIdx.x);     // visible after the first region's barrier
     __shared__ unsigned long long s_new, s_kmers;
@@ -511,8 +540,11 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
 #endif
     for (uint64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
         const uint64_t r = HOT ? hot_list[1 + w] : w;
-        uint64_t n_recs = 0;                                            // block-uniform (scalar loads)
-        for (uint32_t q = 0; q < n_sets; ++q) n_recs += sets[q].base[r + 1] - sets[q].base[r];
+        SetTickets<(uint32_t)GRP> tk;                                   // this region's share of every set (per wave, in registers)
+        tk.build(sets, n_sets, r, (uint32_t)tid & 63u);
+        uint64_t n_recs = tk.cnt;                                       // block-uniform after the reduction
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n_recs += __shfl_xor(n_recs, o, 64);
         const uint32_t narrow_bucket = (NARROW || TOP8) ? (uint32_t)r / narrow_rps : 0u;
         if (n_recs == 0) {                                              // block-uniform
             if (!HOT && table_is_empty == 2) {    // lazy kq_clear: this launch initialises every region, also the ones without records
@@ -543,15 +575,6 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) img_load(s_img, tid + j * P3_THREADS, v[j].x, v[j].y);
         }
         if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = P3_THREADS / 64; }
-        if (tid < 64) {                                                 // wave 0: ticket ranges of the sets (n_sets <= 64 lanes)
-            uint64_t lo_q = 0; uint32_t cnt_q = 0;
-            if (tid < (int)n_sets) { lo_q = sets[tid].base[r]; cnt_q = (uint32_t)(sets[tid].base[r + 1] - lo_q); }     // a region holds < 2^32 records of one set
-            uint32_t incl = (cnt_q + (uint32_t)GRP - 1) / (uint32_t)GRP;
-#pragma unroll
-            for (int o = 1; o < P3_MAX_SETS; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (tid >= o) incl += v; }
-            if (tid < (int)n_sets) { s_set_lo[tid] = lo_q; s_set_cnt[tid] = cnt_q; s_set_grp[tid + 1] = incl; }
-            if (tid == 0) s_set_grp[0] = 0;
-        }
         __syncthreads();
         KQ_STAMP(0);                                                    // region_base load + image init/load + barrier
         uint32_t n_new = 0, n_ok = 0;
@@ -652,25 +675,20 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
         uint32_t nxt_aux[PF];
         // groups of PF*64 records are handed to waves from an LDS ticket: waves that hit long probe
         // chains or contended slots take fewer groups, so all waves reach the barrier together.
-        // Ticket g lies in set q with s_set_grp[q] <= g < s_set_grp[q + 1] (wave-uniform search over a few sets).
         const uint32_t lane = tid & 63;
-        const uint32_t n_grp = s_set_grp[n_sets];
+        const uint32_t n_grp = tk.n_grp;
         uint32_t cur_n = 0;                                            // records in the group whose loads are in flight
         auto fetch = [&](uint32_t g, uint32_t& n) {                     // issues the loads of ticket g (or of a valid dummy when g is past the end)
-            uint32_t q = 0;
-            if (g < n_grp) { while (g >= s_set_grp[q + 1]) ++q; }
-            else { while (s_set_cnt[q] == 0) ++q; g = s_set_grp[q]; }  // n_recs > 0: some set is not empty
-            q = __builtin_amdgcn_readfirstlane(q);
-            const uint32_t off = (g - s_set_grp[q]) * (uint32_t)GRP, cnt = s_set_cnt[q];
-            const uint64_t lo_q = s_set_lo[q];
+            uint32_t q, off, cnt; uint64_t lo_q;
+            tk.locate(g, q, off, cnt, lo_q);
             const uint64_t* rp = sets[q].recs;
             const uint8_t* ap = sets[q].aux;
             n = min(cnt - off, (uint32_t)GRP);
 #pragma unroll
             for (int qq = 0; qq < PF; ++qq) {
                 const uint64_t j = lo_q + min(off + (uint32_t)qq * 64u + lane, cnt - 1u);      // unconditional, index clamped
-                nxt_rec[qq] = NARROW ? (uint64_t)reinterpret_cast<const uint32_t*>(rp)[j] : rp[j];
-                nxt_aux[qq] = HAS_AUX ? ap[j] : 0u;
+                nxt_rec[qq] = NARROW ? (uint64_t)ld_global(reinterpret_cast<const uint32_t*>(rp) + j) : ld_global(rp + j);
+                nxt_aux[qq] = HAS_AUX ? ld_global(ap + j) : 0u;
             }
         };
         uint32_t g_cur = tid >> 6;
@@ -752,6 +770,219 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
         }
         __syncthreads();
         KQ_STAMP(4);                                                    // final barrier
+    }
+}
+
+// rstart[r] = ceil(r 2^32 / R): the first value of the top 32 hash bits that falls into region r
+__global__ __launch_bounds__(256) void k_region_starts(uint32_t* __restrict__ out, uint64_t R) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= R; r += (uint64_t)gridDim.x * blockDim.x)
+        out[r] = r < R ? (uint32_t)(((r << 32) + R - 1) / R) : 0xFFFFFFFFu;
+}
+
+// P3 for FMT_NARROW records (k <= 21, the default k; ordinary regions only -- skewed ones go to hot_list and the
+// generic folding kernel).  Same job as k_count_regions<FMT_NARROW, false>, with a compact LDS image and 32-bit keys:
+//   s_a[slot] = key31 | cnt << 32     key31 = the hash bits that region r does not imply: (top 32 hash bits - rstart[r])
+//                                     << 10 | the 10 hash bits below them (2k - log2 R <= 31 bits: R >= 2048, k <= 21);
+//                                     low word 0xFFFFFFFF = free.  cnt = instances (bit 31 = arrived as a tombstone).
+//   s_e[slot] = the eight u8 edge counters
+// 32 KiB per region instead of 48: four workgroups per CU; a probe reads the key AND the count in one word, the count
+// add returns the tier decision from the same word, and a record turns into its key with three 32-bit operations
+// (no 64-bit hash is rebuilt).  Per record: 2 LDS reads (two slots of the probe sequence) + 2 LDS atomics.
+constexpr uint32_t N32_EMPTY = 0xFFFFFFFFu, N32_TOMB = 1u << 31;
+#ifndef KQ_N32_OCC
+#define KQ_N32_OCC 6
+#endif
+template <int KC>
+__global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(TableView t, const P3Set* __restrict__ sets, uint32_t n_sets, int table_is_empty,
+                                                                      unsigned long long* __restrict__ hot_list, uint32_t rps) {
+    constexpr int PF = KQ_P3_PF;
+    constexpr uint32_t GRP = 64u * PF;
+    __shared__ uint64_t s_a[REGION_SLOTS];
+    __shared__ uint64_t s_e[REGION_SLOTS];
+    __shared__ uint64_t s_lut[64];
+    if (threadIdx.x < 64) s_lut[threadIdx.x] = idx6_to_pack(threadIdx.x);     // visible after the first region's barrier
+    __shared__ unsigned int s_new, s_kmers, s_grp;
+    constexpr int HC_LDS = 64;
+    __shared__ uint64_t s_hckey[HC_LDS];
+    __shared__ uint32_t s_hccnt[HC_LDS][8];
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t k = KC ? KC : t.k;
+    const uint32_t off_shift = 42 - 2 * k;                              // k <= 21
+    for (uint64_t r = blockIdx.x; r < t.n_regions; r += gridDim.x) {
+        SetTickets<GRP> tk;
+        tk.build(sets, n_sets, r, lane);
+        uint64_t n_recs = tk.cnt;                                       // block-uniform after the reduction
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n_recs += __shfl_xor(n_recs, o, 64);
+        ulonglong2* gimg = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
+        if (n_recs == 0) {
+            if (table_is_empty == 2)                                    // lazy kq_clear: this launch initialises every region
+                for (int i = tid; i < (int)REGION_SLOTS; i += P3_THREADS) gimg[i] = make_ulonglong2(0ull, 0ull);
+            continue;
+        }
+        if (n_recs > 32ull * REGION_SLOTS) {                            // skewed region: the folding kernel takes it
+            if (tid == 0) hot_list[1 + atomicAdd(&hot_list[0], 1ull)] = r;
+            continue;
+        }
+        const uint32_t bucket = (uint32_t)r / rps;
+        const uint32_t start_r = t.rstart[r];
+        const uint32_t top_base = (bucket << (32 - NARROW_CBITS)) - start_r;       // (top 32 hash bits of a record) - rstart[r] = top_base + (u32 >> 8)
+        if (tid < HC_LDS) {
+            s_hckey[tid] = EMPTY_KEY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_hccnt[tid][e] = 0;
+        }
+        if (table_is_empty) {
+            for (int i = tid; i < (int)REGION_SLOTS; i += P3_THREADS) { s_a[i] = (uint64_t)N32_EMPTY; s_e[i] = 0; }
+        } else {
+            ulonglong2 v[REGION_SLOTS / P3_THREADS];
+#pragma unroll
+            for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) v[j] = gimg[tid + j * P3_THREADS];
+#pragma unroll
+            for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) {
+                const uint64_t w0 = v[j].x;                             // rem56 | cov8 << 56, rem = hash >> 8
+                uint64_t a = (uint64_t)N32_EMPTY;
+                if (w0) {
+                    const uint32_t key = (((uint32_t)(w0 >> 24) - start_r) << 10) | ((uint32_t)(w0 >> 14) & 1023u);
+                    const uint32_t c = (uint32_t)(w0 >> COV_SHIFT);
+                    a = (uint64_t)key | ((uint64_t)(c == COV8_TOMB ? (N32_TOMB | LOW_TIER_MAX) : c) << 32);
+                }
+                s_a[tid + j * P3_THREADS] = a;
+                s_e[tid + j * P3_THREADS] = v[j].y;
+            }
+        }
+        if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = P3_THREADS / 64; }
+        __syncthreads();
+        uint32_t n_new = 0, n_ok = 0;
+        // hash of a key of this region (high-copy tier only)
+        auto hash_of = [&](uint32_t key) -> uint64_t { return ((uint64_t)(start_r + (key >> 10)) << 32) | ((uint64_t)(key & 1023u) << 22); };
+        auto add_wide = [&](uint32_t key31, uint64_t pack) {
+            const uint64_t h = hash_of(key31);
+            const uint64_t key = key_of_hash(h, t.k);
+            uint32_t e[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) e[w] = (uint32_t)(pack >> (8 * w)) & 1u;
+            int hslot = -1;
+            uint32_t hp = (uint32_t)(h >> 40) & (HC_LDS - 1);
+            for (int probe = 0; probe < HC_LDS; ++probe, hp = (hp + 1) & (HC_LDS - 1)) {
+                uint64_t cur = __hip_atomic_load(&s_hckey[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == EMPTY_KEY) cur = atomicCAS((unsigned long long*)&s_hckey[hp], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                if (cur == EMPTY_KEY || cur == key) { hslot = (int)hp; break; }
+            }
+            if (hslot >= 0) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd(&s_hccnt[hslot][w], e[w]);
+            } else {
+                hc_add(t, h, 0, 0, e);
+            }
+        };
+        // Records are double-buffered in registers (unconditional loads, index clamped); groups of GRP records are handed
+        // to waves from an LDS ticket, so waves that hit long probe chains take fewer groups.
+        uint32_t nxt_rec[PF], nxt_aux[PF];
+        uint32_t cur_n = 0;
+        auto fetch = [&](uint32_t g, uint32_t& n) {
+            uint32_t q, off, cnt; uint64_t lo_q;
+            tk.locate(g, q, off, cnt, lo_q);
+            const uint32_t* rp = reinterpret_cast<const uint32_t*>(sets[q].recs);
+            const uint8_t* ap = sets[q].aux;
+            n = min(cnt - off, GRP);
+#pragma unroll
+            for (int qq = 0; qq < PF; ++qq) {
+                const uint64_t j = lo_q + min(off + (uint32_t)qq * 64u + lane, cnt - 1u);
+                nxt_rec[qq] = ld_global(rp + j);
+                nxt_aux[qq] = ld_global(ap + j);
+            }
+        };
+        uint32_t g_cur = tid >> 6;
+        fetch(g_cur, cur_n);
+        while (g_cur < tk.n_grp) {                                      // wave-uniform
+            uint32_t cur_rec[PF], cur_aux[PF];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) { cur_rec[q] = nxt_rec[q]; cur_aux[q] = nxt_aux[q]; }
+            uint32_t g_nxt = 0;
+            if (lane == 0) g_nxt = atomicAdd(&s_grp, 1u);
+            g_nxt = __builtin_amdgcn_readfirstlane(g_nxt);
+            const uint32_t n_cur = cur_n;
+            fetch(g_nxt, cur_n);
+            g_cur = g_nxt;
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const bool active = (uint32_t)q * 64u + lane < n_cur;
+                const uint32_t m = cur_rec[q], aux = cur_aux[q];
+                const uint32_t low = ((m & 0xFFu) << 2) | (aux & 3u);   // the 10 hash bits below the top 32
+                const uint32_t key = ((top_base + (m >> 8)) << 10) | low;
+                uint32_t pos = KC == 21 ? (((m << 2) | (aux & 3u)) & (REGION_SLOTS - 1))
+                                        : (uint32_t)(((((uint64_t)bucket << 34) | ((uint64_t)m << 2) | (aux & 3u)) >> off_shift) & (REGION_SLOTS - 1));
+                const uint64_t pack = s_lut[(aux >> 2) & 63u];
+                // find-or-claim: two slots of the probe sequence per LDS round trip; one CAS site
+                uint32_t slot = active ? REGION_SLOTS : 0u;             // REGION_SLOTS = still looking
+                uint32_t probes = 0;
+#ifdef KQ_ABL
+                if (KQ_ABL & 4) slot = active ? pos : 0u;               // ablation build (timing only, never shipped): no probe
+#endif
+                while (slot == REGION_SLOTS) {
+                    const uint32_t i0 = pos, i1 = (pos + 1) & (REGION_SLOTS - 1);
+                    const uint32_t c0 = (uint32_t)__hip_atomic_load(&s_a[i0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t c1 = (uint32_t)__hip_atomic_load(&s_a[i1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (c0 == key) { slot = i0; break; }
+                    const bool free0 = c0 == N32_EMPTY;
+                    if (!free0 && c1 == key) { slot = i1; break; }
+                    if (free0 || c1 == N32_EMPTY) {
+                        const uint32_t ic = free0 ? i0 : i1;
+                        const uint32_t got = (uint32_t)atomicCAS((unsigned long long*)&s_a[ic], (unsigned long long)N32_EMPTY, (unsigned long long)key);
+                        if (got == N32_EMPTY) { ++n_new; slot = ic; break; }
+                        if (got == key) { slot = ic; break; }
+                        continue;                                       // another key took it: look at the pair again
+                    }
+                    pos = (pos + 2) & (REGION_SLOTS - 1);
+                    if ((probes += 2) >= REGION_SLOTS) { atomicOr(&t.st->err_table_full, 1u); slot = REGION_SLOTS + 1; }
+                }
+                if (active && slot < REGION_SLOTS) {
+                    ++n_ok;
+#ifdef KQ_ABL
+                    const uint64_t old = (KQ_ABL & 2) ? 0 : atomicAdd((unsigned long long*)&s_a[slot], 1ull << 32);
+                    if (KQ_ABL & 1) continue;
+#else
+                    const uint64_t old = atomicAdd((unsigned long long*)&s_a[slot], 1ull << 32);
+#endif
+                    if (pack) {
+                        if ((uint32_t)(old >> 32) < LOW_TIER_MAX) atomicAdd((unsigned long long*)&s_e[slot], (unsigned long long)pack);
+                        else add_wide(key, pack);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { n_new += __shfl_down(n_new, o, 64); n_ok += __shfl_down(n_ok, o, 64); }
+        if (lane == 0) { if (n_new) atomicAdd(&s_new, n_new); if (n_ok) atomicAdd(&s_kmers, n_ok); }
+        __syncthreads();
+        if (tid < HC_LDS && s_hckey[tid] != EMPTY_KEY) {            // flush the region's high-copy sums: one entry per k-mer
+            HcSlot* hs = hc_upsert(t, s_hckey[tid]);
+            if (!hs) atomicOr(&t.st->err_hc_full, 1u);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (s_hccnt[tid][e]) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)s_hccnt[tid][e]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) {
+            const int i = tid + j * P3_THREADS;
+            const uint64_t a = s_a[i];
+            ulonglong2 o = make_ulonglong2(0ull, 0ull);
+            if ((uint32_t)a != N32_EMPTY) {
+                const uint32_t key = (uint32_t)a, cw = (uint32_t)(a >> 32), c = cw & ~N32_TOMB;
+                uint64_t cov8 = (cw & N32_TOMB) ? COV8_TOMB : c;
+                if (c > LOW_TIER_MAX) { cov8 = COV8_TOMB; hc_add(t, hash_of(key), c - LOW_TIER_MAX, 0, nullptr); }
+                o = make_ulonglong2((((uint64_t)(start_r + (key >> 10))) << 24) | ((uint64_t)(key & 1023u) << 14) | (cov8 << COV_SHIFT), s_e[i]);
+            }
+            gimg[i] = o;
+        }
+        if (tid == 0) {
+            if (s_new) atomicAdd(&t.st->slots_used, (unsigned long long)s_new);
+            if (s_kmers) atomicAdd(&t.st->kmers_added, (unsigned long long)s_kmers);
+        }
+        __syncthreads();
     }
 }
 

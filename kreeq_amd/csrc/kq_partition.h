@@ -140,11 +140,12 @@ __device__ __forceinline__ uint32_t narrow_bin(const LevelCfg& lv, uint32_t b, u
 // LDS of one multisplit workgroup.  NBC = bin capacity (incl. the discard bin): 512 keeps the whole
 // struct at 48 KiB (three workgroups per CU) and covers the usual fan-outs; 2048 (72-76 KiB, two per
 // CU) is the general case.
-template <int NBC, int FMT>
+template <int NBC, int FMT, int TILE = MS_TILE>
 struct MsShared {
-    uint64_t stage[MS_TILE];                 // 32 KiB; narrow records are staged as ONE word: u32 | bin << 32 | byte << 48
-    uint16_t sbin[FMT != FMT_NARROW ? MS_TILE : 4];  //  8 KiB
-    uint8_t  saux[FMT == FMT_WIDE ? MS_TILE : 8];    //  4 KiB   (WIDE records only)
+    static constexpr int tile = TILE;
+    uint64_t stage[TILE];                    // 32 KiB; narrow records are staged as ONE word: u32 | bin << 32 | byte << 48
+    uint16_t sbin[FMT != FMT_NARROW ? TILE : 4];     //  8 KiB
+    uint8_t  saux[FMT == FMT_WIDE ? TILE : 8];       //  4 KiB   (WIDE records only)
     uint32_t hist[NBC];
     uint32_t loff[NBC];
     uint32_t gbase[NBC];                     // output cursors: a partition pass handles < 2^32 records (host-checked)
@@ -208,7 +209,7 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     for (uint32_t b = tid; b <= nb; b += THREADS) s.hist[b] = 0;
     __syncthreads();
     KQ_MS_STAMP(s, 1);                            // zero hist + barrier
-    static_assert(THREADS * ITEMS <= MS_TILE, "round size");
+    static_assert(THREADS * ITEMS <= S::tile, "round size");
     // FMT_NARROW: rec[i] is the staged word itself (u32 | bin << 32 | byte << 48, narrow_word()); aux[] and
     // bin[] are not read, which saves the caller 2 x ITEMS registers
     uint32_t rank[ITEMS];

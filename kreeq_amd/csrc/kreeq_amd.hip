@@ -49,6 +49,7 @@ struct kq_handle {
     uint64_t n_regions = 0;
     HcSlot* hc = nullptr;
     uint64_t hc_cap = 0;
+    uint32_t* rstart = nullptr;      // device: first top-32 hash value of every region (n_regions + 1 entries)
     DevState* st = nullptr;          // device
     DevState* st_host = nullptr;     // pinned mirror
     // scratch (grown on demand)
@@ -84,6 +85,7 @@ struct kq_handle {
     TableView view() const {
         TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; v.k = (uint32_t)k;
         v.rps = k >= HI_K ? (uint32_t)(n_regions >> 8) : 0u;
+        v.rstart = rstart;
         return v;
     }
     uint64_t n_slots() const { return n_regions << REGION_SHIFT; }
@@ -123,12 +125,15 @@ static void materialize(kq_handle* h) {
     clear_main(h, h->slots, h->n_slots());
     h->slots_dirty = false;
 }
-static int alloc_main(kq_handle* h, uint64_t n_regions, Slot** out) {
+static int alloc_main(kq_handle* h, uint64_t n_regions, Slot** out, uint32_t** rstart_out) {
     Slot* p = nullptr;
+    uint32_t* rs = nullptr;
     size_t bytes = (size_t)(n_regions << REGION_SHIFT) * sizeof(Slot);
     HIPC(hipMalloc((void**)&p, bytes));
+    if (hipMalloc((void**)&rs, (size_t)(n_regions + 1) * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(p); return fail(KQ_ERR_NOMEM, "region index allocation failed"); }
     clear_main(h, p, n_regions << REGION_SHIFT);
-    *out = p;
+    hipLaunchKernelGGL(k_region_starts, dim3(grid_for(h, n_regions + 1, 256)), dim3(256), 0, h->stream, rs, n_regions);
+    *out = p; *rstart_out = rs;
     return KQ_OK;
 }
 static int alloc_hc(kq_handle* h, uint64_t cap, HcSlot** out) {
@@ -169,16 +174,19 @@ static int grow_main(kq_handle* h, uint64_t need_slots) {
     while (want < need_slots) want *= 2;
     const uint64_t new_regions = want >> REGION_SHIFT;
     Slot* fresh = nullptr;
-    int rc = alloc_main(h, new_regions, &fresh);
+    uint32_t* fresh_rs = nullptr;
+    int rc = alloc_main(h, new_regions, &fresh, &fresh_rs);
     if (rc) return rc == KQ_ERR_NOMEM ? fail(KQ_ERR_TABLE_FULL, "cannot grow k-mer table to %llu slots: out of device memory",
                                              (unsigned long long)want) : rc;
     Slot* old = h->slots; const uint64_t n_old = h->n_slots();
     const TableView old_view = h->view();
-    h->slots = fresh; h->n_regions = new_regions;
+    uint32_t* old_rs = h->rstart;
+    h->slots = fresh; h->n_regions = new_regions; h->rstart = fresh_rs;
     if (h->slots_dirty) h->slots_dirty = false;     // lazily cleared table: nothing to move, and the fresh array is clean
     else hipLaunchKernelGGL(k_rehash, dim3(grid_for(h, n_old, 256)), dim3(256), 0, h->stream, h->view(), old_view);
     HIPC(hipStreamSynchronize(h->stream));
     HIPC(hipFree(old));
+    if (old_rs) HIPC(hipFree(old_rs));
     return KQ_OK;
 }
 static int grow_hc(kq_handle* h, uint64_t need) {
@@ -324,7 +332,7 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
             const uint64_t unit = 256ull << sbits;
             regions = (regions + unit - 1) / unit * unit;
         }
-        rc = alloc_main(h, regions, &h->slots); if (rc) break;
+        rc = alloc_main(h, regions, &h->slots, &h->rstart); if (rc) break;
         h->n_regions = regions;
         uint64_t hc = 1u << 16;
         rc = alloc_hc(h, hc, &h->hc); if (rc) break;
@@ -341,6 +349,7 @@ void kq_destroy(kq_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->slots) (void)hipFree(h->slots);
+    if (h->rstart) (void)hipFree(h->rstart);
     if (h->hc) (void)hipFree(h->hc);
     if (h->st) (void)hipFree(h->st);
     if (h->st_host) (void)hipHostFree(h->st_host);
@@ -730,7 +739,15 @@ static int flush_pending(kq_handle* h) {
 #define KQ_P3(F) do { \
         hipLaunchKernelGGL((k_count_regions<F, false>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, h->pend_aux_fmt, empty, hot, rps); \
         hipLaunchKernelGGL((k_count_regions<F, true>), grid_hot, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, h->pend_aux_fmt, empty, hot, rps); } while (0)
-    if (fmt == FMT_NARROW) KQ_P3(FMT_NARROW);
+#ifdef KQ_NO_N32
+    if (fmt == FMT_NARROW) KQ_P3(FMT_NARROW); else
+#endif
+    if (fmt == FMT_NARROW) {
+        // ordinary regions: the compact 32-bit-key kernel; skewed ones: the generic folding kernel
+        if (h->k == 21) hipLaunchKernelGGL((k_count_regions_n32<21>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps);
+        else hipLaunchKernelGGL((k_count_regions_n32<0>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps);
+        hipLaunchKernelGGL((k_count_regions<FMT_NARROW, true>), grid_hot, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, h->pend_aux_fmt, empty, hot, rps);
+    }
     else if (fmt == FMT_TOP8) KQ_P3(FMT_TOP8);
     else if (fmt == FMT_WIDE) KQ_P3(FMT_WIDE);
     else KQ_P3(FMT_PACK8);
