@@ -29,30 +29,28 @@ def main():
     ap.add_argument("-k", type=int, default=21)
     ap.add_argument("--batch-reads", type=int, default=2_000_000)
     ap.add_argument("--oracle", action="store_true")
+    ap.add_argument("--pending-bytes", type=int, default=-1)
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
     from kreeq_amd import KreeqDB
 
+    from kreeq_amd import synth
+
     dev = torch.device("cuda", 0)
     G = int(args.genome_mbp * 1e6)
     L, k = args.read_len, args.k
     n_reads = int(G * args.coverage / L)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1)
-    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    genome = torch.randint(0, 4, (G,), dtype=torch.uint8, device=dev, generator=gen)
-    # assembly = genome with substitutions
-    gen.manual_seed(3)
-    mut = torch.rand(G, device=dev, generator=gen) < args.asm_err
-    asm_codes = torch.where(mut, (genome + torch.randint(1, 4, (G,), dtype=torch.uint8, device=dev, generator=gen)) & 3, genome)
-    assembly = acgt[asm_codes.long()]
-    n_sub = int(mut.sum())
+    genome = synth.genome_dev(G, dev, seed=1)
+    asm_codes, n_sub = synth.mutate_dev(genome, args.asm_err, seed=3)      # assembly = genome with substitutions
+    assembly = synth.ascii_dev(asm_codes)
+    del asm_codes
 
     # expected distinct: genome k-mers + ~k novel k-mers per read error
     hint = int(1.1 * (G + n_reads * L * args.err * k))
     db = KreeqDB(k, 128, capacity_hint=hint)
     db.set_option("trust_capacity", 1)
+    db.set_option("pending_bytes", args.pending_bytes)
     stream = torch.cuda.Stream(dev)
     db.set_stream(stream.cuda_stream)
 
@@ -62,13 +60,13 @@ def main():
         oracle = O.OracleDB(k, 128)
         cores = min(128, len(os.sched_getaffinity(0)))
 
+    gen = torch.Generator(device=dev)
     gen.manual_seed(2)
-    ar = torch.arange(L, device=dev)
     t_count = t_cpu = 0.0
     done = 0
     with torch.cuda.stream(stream):
         # allocation warm-up outside the timed region: a batch of N's of the same size makes the library size its
-        # partition scratch (16 B per k-mer start; hipMalloc of ~20 GB takes ~0.7 s once) and inserts nothing
+        # partition scratch (hipMalloc of several GB takes a few hundred ms once) and inserts nothing
         nb = min(args.batch_reads, n_reads)
         dummy = torch.full((nb * (L + 1) - 1,), ord("N"), dtype=torch.uint8, device=dev)
         db.count_batch_dev(dummy.data_ptr(), dummy.numel())
@@ -76,20 +74,11 @@ def main():
         del dummy
         while done < n_reads:
             n = min(args.batch_reads, n_reads - done)
-            starts = torch.randint(0, G - L + 1, (n,), device=dev, generator=gen)
-            codes = genome[(starts[:, None] + ar[None, :])]
-            rev = torch.rand(n, device=dev, generator=gen) < 0.5
-            codes = torch.where(rev[:, None], 3 - codes.flip(1), codes)
-            e = torch.rand((n, L), device=dev, generator=gen) < args.err
-            codes = torch.where(e, (codes + torch.randint(1, 4, (n, L), dtype=torch.uint8, device=dev, generator=gen)) & 3, codes)
-            batch = torch.full((n, L + 1), 10, dtype=torch.uint8, device=dev)
-            batch[:, :L] = acgt[codes.long()]
-            flat = batch.reshape(-1)[:-1].contiguous()
-            del starts, codes, rev, e, batch
+            flat = synth.reads_dev(genome, n, L, gen, err=args.err)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             db.count_batch_dev(flat.data_ptr(), flat.numel())
-            db.sync()
+            torch.cuda.synchronize(dev)             # the batch is consumed; its records may stay pending (no table pass yet)
             t_count += time.perf_counter() - t0
             if oracle is not None:
                 host = flat.cpu().numpy().tobytes()
@@ -98,6 +87,9 @@ def main():
                 t_cpu += time.perf_counter() - t0
             done += n
             print(f"counted {done}/{n_reads} reads  gpu {t_count:.2f} s" + (f"  cpu {t_cpu:.1f} s" if oracle else ""), flush=True)
+        t0 = time.perf_counter()
+        db.sync()                                   # applies what is still pending
+        t_count += time.perf_counter() - t0
         st = db.summary()
         ctr = torch.zeros(3, dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
