@@ -139,6 +139,9 @@ const char* kq_last_error(void);
 int  kq_abi_version(void);
 /* 1 when a gfx950-capable device is visible to the HIP runtime. */
 int  kq_device_available(void);
+/* Free / total HBM of a device in bytes (what gfalibs' get_mem_total / freeMemory are to the reference's
+ * memory-bounded mode, src/main.cpp:433, src/kreeq.cpp:59-63): lets the host choose how many map ranges to count in. */
+int  kq_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* ---- hot loop 1 + 2: count ---------------------------------------------------------------- */
 

@@ -13,7 +13,7 @@ DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw",
 
 # every symbol include/kreeq_amd.h declares
 SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_get_profile", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_flush", "kq_get_info", "kq_last_error",
-           "kq_abi_version", "kq_device_available", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
+           "kq_abi_version", "kq_device_available", "kq_device_memory", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
            "kq_emit_partitioned_dev", "kq_emit_packed_dev", "kq_insert_packed_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
            "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_merge", "kq_import", "kq_export"]
 
@@ -89,6 +89,7 @@ def load():
     L.kq_flush.argtypes = [vp]
     L.kq_get_info.argtypes = [vp, C.POINTER(Info)]
     L.kq_last_error.restype = C.c_char_p
+    L.kq_device_memory.argtypes = [ci, C.POINTER(u64), C.POINTER(u64)]
     L.kq_count_batch.argtypes = [vp, vp, u64]
     L.kq_count_batch_dev.argtypes = [vp, vp, u64]
     L.kq_emit_records.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
@@ -119,6 +120,13 @@ def _p(a):
 
 def device_available():
     return bool(load().kq_device_available())
+
+
+def device_memory(device=0):
+    """(free, total) HBM bytes"""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    _check(load().kq_device_memory(device, C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 class KreeqDB:

@@ -294,6 +294,18 @@ int kq_device_available(void) {
     return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
+int kq_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(KQ_ERR_INVALID, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(KQ_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(KQ_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    HIPC(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPC(hipMemGetInfo(&f, &t));
+    *free_bytes = f; *total_bytes = t;
+    return KQ_OK;
+}
+
 int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capacity_hint) {
     if (!out) return fail(KQ_ERR_INVALID, "out is null");
     *out = nullptr;

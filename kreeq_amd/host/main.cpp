@@ -38,7 +38,7 @@ struct UserInput {                       // reference UserInputKreeq (include/in
     int kmerDepth = -1, maxSpan = 5, maxThreads = 0;
     double maxMem = 0;
     int device = 0;
-    int passes = 1;                      // --passes: count the maps in this many ranges (memory-bounded mode)
+    int passes = 0;                      // --passes: count the maps in this many ranges (memory-bounded mode); 0 = as many as the HBM asks for
 };
 
 int verbose_flag = 0, cmd_flag = 0;
@@ -257,7 +257,9 @@ struct Engine {
         const bool per_base_out = (ext == "kwig" || ext == "bkwig" || ext == "bed" || ext == "csvtable");
         if (ext == "gfa" || ext == "gfa2" || ext == "gfa.gz" || ext == "gfa2.gz" || ext == "vcf")
             die("Error: ." + ext + " output (variant search) is not supported by this build");
-        if (ext != "kreeq" && ext != "hist" && ui.mode == 0) validate_sequences(per_base_out);
+        // the reference's first switch has no case for .kreeq / .hist, so they fall to `default:` like every other
+        // extension and validate too (src/kreeq-output.cpp:62-72); validateSequences returns at once without -f
+        if (ui.mode == 0) validate_sequences(per_base_out);
         if (ext == "kreeq") { write_kreeq_db(ui.outFile); verbose("Database written"); }
         else if (ext == "kwig") write_kwig(ui.outFile);
         else if (ext == "bkwig") write_bkwig(ui.outFile);
@@ -267,6 +269,26 @@ struct Engine {
 };
 
 uint64_t file_size(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0; }
+uint64_t db_bytes(const std::string& dir, int map_count) {
+    uint64_t b = file_size(dir + "/.map.hc.bin");
+    for (int m = 0; m < map_count; ++m) b += file_size(dir + "/.map." + std::to_string(m) + ".bin");
+    return b;
+}
+
+// distinct k-mers a read set may hold, from its size on disk (a FASTQ record spends about half its bytes on bases,
+// a gzipped one is ~4x smaller; at 30x coverage and 0.5 % errors about a fifth of the k-mer instances are distinct)
+uint64_t distinct_estimate(uint64_t read_bytes) { return read_bytes / 2 + (1 << 20); }
+// Map ranges to count in (the reference's computeMapRange, src/kreeq.cpp:59-63, bounds its maps by -m / 90 % of the
+// RAM; here the bound is the HBM): the table (16 B per slot at load <= 0.7) plus the partition scratch and the
+// pending-set arena should stay within 60 % of what is free, or of -m <GB> when that is smaller.
+int passes_for(const UserInput& ui, uint64_t distinct) {
+    uint64_t free_b = 0, total_b = 0;
+    if (kq_device_memory(ui.device, &free_b, &total_b) != KQ_OK) return 1;
+    double budget = 0.6 * (double)free_b;
+    if (ui.maxMem > 0) budget = std::min(budget, ui.maxMem * 1e9);
+    const double table = (double)distinct / 0.7 * 16.0;
+    return (int)std::max(1.0, std::min(128.0, std::ceil(table / budget)));
+}
 
 // Read-batch size handed to kq_count_batch: the partitioned count streams the table once per batch, so large
 // inputs (large tables) get batches of up to 1 GiB of bases; small inputs keep 128 MiB for parser/GPU overlap.
@@ -278,26 +300,28 @@ static size_t batch_bytes_for(uint64_t input_bytes) {
 // every range -- the GPU counterpart of the reference's map-range loop (computeMapRange /
 // loadMapRange, src/kreeq.cpp:59-74) and of its spill-to-disk behaviour under -m.  Only 1/passes of
 // the table is resident at a time; summary numbers and QV counters add up over the disjoint ranges.
+unsigned parser_threads(const UserInput& ui) { return ui.maxThreads > 0 ? (unsigned)ui.maxThreads : std::max(1u, std::thread::hardware_concurrency()); }
+
 int run_passes(Engine& e) {
     UserInput& ui = e.ui;
     e.k = ui.kmerLen;
     if (ui.passes > e.map_count) ui.passes = e.map_count;
     uint64_t bytes = 0;
     for (auto& f : ui.inReads) bytes += file_size(f) * (file_ext(f).find("gz") != std::string::npos ? 4 : 1);
-    e.create(std::min<uint64_t>((bytes / 2) / (uint64_t)ui.passes + (1 << 20), 1ull << 31));
+    e.create(distinct_estimate(bytes) / (uint64_t)ui.passes + (1 << 20));
     std::string ext = "stdout";
     if (ui.outFile != "") ext = file_ext("." + ui.outFile);
     if (ext == "gfa" || ext == "gfa2" || ext == "gfa.gz" || ext == "gfa2.gz" || ext == "vcf")
         die("Error: ." + ext + " output (variant search) is not supported by this build");
     if (!ui.inSequence.empty()) load_genome(ui.inSequence, e.genome);
     const bool want_stats = ui.outFile.find(".") != std::string::npos || ui.outFile == "" || ext == "kreeq";
-    const bool want_validate = ext != "kreeq" && ext != "hist" && !ui.inSequence.empty();
+    const bool want_validate = !ui.inSequence.empty();              // every extension validates (src/kreeq-output.cpp:62-72)
     const bool per_base_out = (ext == "kwig" || ext == "bkwig" || ext == "bed" || ext == "csvtable");
     if (ext == "hist") die("Error: .hist output needs a single pass");
     if (want_validate && per_base_out) e.per_base.assign(e.genome.joined.size(), kq_dbgbase{});
     kq_stats sum{};
     std::vector<kq_entry> hc_all;
-    const unsigned threads = ui.maxThreads > 0 ? (unsigned)ui.maxThreads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned threads = parser_threads(ui);
     for (int p = 0; p < ui.passes; ++p) {
         const int lo = (int)((long long)p * e.map_count / ui.passes), hi = (int)((long long)(p + 1) * e.map_count / ui.passes);
         verbose("Pass " + std::to_string(p + 1) + "/" + std::to_string(ui.passes) + ": maps [" + std::to_string(lo) + "," + std::to_string(hi) + ")");
@@ -342,15 +366,19 @@ int run(UserInput& ui) {
     if (ui.outFile.find(".kreeq") != std::string::npos) e.ui.prefix = ui.outFile;        // src/input.cpp:78-79
     switch (ui.mode) {
         case 0: {                                                    // src/input.cpp:86-118
-            if (!ui.inReads.empty() && ui.passes > 1) return run_passes(e);
             if (!ui.inReads.empty()) {
-                e.k = ui.kmerLen;
                 uint64_t bytes = 0;
                 for (auto& f : ui.inReads) bytes += file_size(f) * (file_ext(f).find("gz") != std::string::npos ? 4 : 1);
-                e.create(std::min<uint64_t>(bytes / 2 + (1 << 20), 1ull << 31));
+                if (ui.passes == 0) {                                // automatic: as many map ranges as the HBM asks for
+                    e.ui.passes = ui.passes = passes_for(ui, distinct_estimate(bytes));
+                    if (ui.passes > 1) verbose("Table of ~" + std::to_string(distinct_estimate(bytes)) + " k-mers does not fit the free HBM: counting in " + std::to_string(ui.passes) + " map ranges");
+                }
+                if (ui.passes > 1) return run_passes(e);
+                e.k = ui.kmerLen;
+                e.create(distinct_estimate(bytes));
                 verbose("Loading input reads.");
                 for (auto& f : ui.inReads)
-                    read_batches_parallel(f, batch_bytes_for(bytes), ui.maxThreads > 0 ? (unsigned)ui.maxThreads : std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
+                    read_batches_parallel(f, batch_bytes_for(bytes), parser_threads(ui),
                                           [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
                 verbose("Reads loaded.");
             } else {                                                 // Input::loadGraph, src/input.cpp:56-74
@@ -382,12 +410,26 @@ int run(UserInput& ui) {
             }
             if (k == 0 || k > 32) { fprintf(stderr, "Invalid kmer length.\n"); exit(1); }
             e.k = k; e.map_count = map_count;
-            std::vector<std::vector<kq_entry>> all(ui.kmerDB.size());
+            // DBG::kunion (src/graph-builder.cpp:297-351): largest database first (:341-344); every further database is
+            // loaded into a table of its own and merged region by region on the device (kq_merge = mergeSubMaps)
+            std::vector<std::pair<uint64_t, size_t>> order;
+            for (size_t i = 0; i < ui.kmerDB.size(); ++i) order.emplace_back(db_bytes(ui.kmerDB[i], map_count), i);
+            std::sort(order.rbegin(), order.rend());
             uint64_t total = 0;
-            for (size_t i = 0; i < ui.kmerDB.size(); ++i) { read_db(ui.kmerDB[i], all[i]); total += all[i].size(); }
+            for (auto& o : order) total += o.first / 24;             // 24-byte slots at load <= 7/8: an upper bound of the entries
             e.create(total + 1024);
             verbose("DBG object generated. Merging.");
-            for (auto& v : all) kq_or_die(kq_import(e.h, v.data(), v.size()));            // DBG::kunion: import == add
+            for (size_t n = 0; n < order.size(); ++n) {
+                std::vector<kq_entry> v;
+                read_db(ui.kmerDB[order[n].second], v);
+                if (n == 0) { kq_or_die(kq_import(e.h, v.data(), v.size())); continue; }
+                kq_handle* src = nullptr;
+                kq_or_die(kq_create(&src, ui.device, k, map_count, v.size() + 1024));
+                kq_or_die(kq_import(src, v.data(), v.size()));
+                kq_or_die(kq_set_option(e.h, KQ_OPT_MERGE_PATH, 2));
+                kq_or_die(kq_merge(e.h, src));
+                kq_destroy(src);
+            }
             e.report();
             break;
         }
@@ -472,7 +514,7 @@ int main(int argc, char** argv) {
                     if (strcmp(long_options[option_index].name, "search-depth") == 0) ui.kmerDepth = atoi(optarg);
                     if (strcmp(long_options[option_index].name, "max-span") == 0) ui.maxSpan = atoi(optarg);
                     if (strcmp(long_options[option_index].name, "device") == 0) ui.device = atoi(optarg);
-                    if (strcmp(long_options[option_index].name, "passes") == 0) ui.passes = std::max(1, atoi(optarg));
+                    if (strcmp(long_options[option_index].name, "passes") == 0) ui.passes = std::max(0, atoi(optarg));
                     break;
                 case 'c':
                     if (!is_number(optarg)) { fprintf(stderr, "input '%s' to option -%c must be a number\n", optarg, optopt); return EXIT_FAILURE; }
@@ -507,10 +549,10 @@ int main(int argc, char** argv) {
                     printf("\t-o --out-format supported extensions:\n");
                     printf("\t\t .kreeq dumps hashmaps to file for reuse; .kwig .bkwig per-base tables; .hist coverage histogram.\n");
                     printf("\t-t --tmp-prefix prefix to temporary directory (unused: the table lives in HBM).\n");
-                    printf("\t-m --max-memory accepted for compatibility.\n");
-                    printf("\t-j --threads <n> parser threads for the read files (default: up to 16).\n");
+                    printf("\t-m --max-memory <GB> HBM the k-mer table may use (default: 60 %% of what is free); bounds the map ranges counted at a time.\n");
+                    printf("\t-j --threads <n> parser threads for the read files (default: all cores).\n");
                     printf("\t--device <n> GPU to use (default 0).\n");
-                    printf("\t--passes <n> count the reads n times, one range of the hash maps per pass (bounds HBM use to 1/n of the table).\n");
+                    printf("\t--passes <n> count the reads n times, one range of the hash maps per pass (HBM use = 1/n of the table); default: as many as -m asks for.\n");
                     printf("\t-v --version software version.\n");
                     printf("\t--cmd print $0 to stdout.\n");
                     exit(0);

@@ -180,3 +180,52 @@ def test_bed_table(cli, tmp_path):
                 li += 1
             i = j
     assert lines[li:] == [""]
+
+
+@pytest.mark.parametrize("ext", ["kreeq", "hist", "unknownext"])
+def test_report_validates_for_every_extension(cli, tmp_path, ext):
+    """DBG::report's first switch has no case for .kreeq / .hist (src/kreeq-output.cpp:62-72): with -f they validate like
+    any other extension and, the output name containing a '.', print the QV table (src/kreeq.cpp:78)"""
+    _, exp = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.0.tst"))
+    out = str(tmp_path / ("o." + ext))
+    got = run(cli, ["validate", "-f", H.golden_input("random1.fasta"), "-r", H.golden_input("random1.fastq"), "-o", out])
+    assert [l for l in got if l] == exp
+    if ext == "kreeq":
+        assert open(os.path.join(out, ".index")).read() == "21\n128\n"
+    if ext == "hist":
+        assert os.path.getsize(out) > 0
+
+
+def test_memory_bound_picks_passes(cli, tmp_path):
+    """-m <GB> bounds the HBM of the table: when it does not fit, the maps are counted in ranges automatically
+    (the reference's computeMapRange loop, src/kreeq.cpp:59-74) and every output stays the same"""
+    from tests.golden.make_golden import decode_db
+
+    _, exp = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.3.tst"))
+    reads = [H.golden_input("random1.fastq"), H.golden_input("random2.fastq")]
+    p = subprocess.run([cli, "validate", "-f", H.golden_input("random1.fasta"), "-r"] + reads + ["-m", "0.001", "--verbose"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert [l for l in p.stdout.split("\n") if l] == exp
+    assert "map ranges" in p.stderr and "Pass 2/" in p.stderr
+    db, single = str(tmp_path / "m.kreeq"), str(tmp_path / "s.kreeq")
+    run(cli, ["validate", "-r"] + reads + ["-o", db, "-m", "0.001"])
+    run(cli, ["validate", "-r"] + reads + ["-o", single])
+    assert decode_db(db) == decode_db(single)
+
+
+def test_union_of_three_goes_through_merge(cli, tmp_path, golden_dbs):
+    """union of three databases: the largest is imported, the others are merged region by region on the device;
+    the result equals counting all reads together"""
+    from tests.golden.make_golden import decode_db
+
+    dbs = []
+    for i, name in enumerate(["random1.fastq", "random2.fastq", "random3.N.fastq"]):
+        d = str(tmp_path / f"d{i}.kreeq")
+        run(cli, ["validate", "-r", H.golden_input(name), "-o", d])
+        dbs.append(d)
+    u, whole = str(tmp_path / "u.kreeq"), str(tmp_path / "w.kreeq")
+    out_u = run(cli, ["union", "-d"] + dbs + ["-o", u])
+    out_w = run(cli, ["validate", "-r"] + [H.golden_input(n) for n in ("random1.fastq", "random2.fastq", "random3.N.fastq")] + ["-o", whole])
+    assert [l for l in out_u if l] == [l for l in out_w if l]
+    assert decode_db(u) == decode_db(whole)
