@@ -1023,6 +1023,7 @@ int kq_emit_partitioned_dev(kq_handle* h, const char* d_bases, uint64_t len, int
     HIPC(hipSetDevice(h->device));
     for (int i = 0; i < n_parts; ++i) part_counts[i] = 0;
     if (len < (uint64_t)h->k) return KQ_OK;
+    if (len - h->k + 1 >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "an owner split handles fewer than 2^32 k-mer starts per call (got %llu): cut the batch", (unsigned long long)(len - h->k + 1));
     if (cap < len - h->k + 1 || !d_keys || !d_edges) return fail(KQ_ERR_CAPACITY, "record buffer too small: need room for %llu records",
                                                                   (unsigned long long)(len - h->k + 1));
     const uint8_t* ab; uint64_t lead;
@@ -1052,6 +1053,7 @@ int kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_pa
     HIPC(hipSetDevice(h->device));
     for (int i = 0; i < n_parts; ++i) part_counts[i] = 0;
     if (len < (uint64_t)h->k) return KQ_OK;
+    if (len - h->k + 1 >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "an owner split handles fewer than 2^32 k-mer starts per call (got %llu): cut the batch", (unsigned long long)(len - h->k + 1));
     if (cap < len - h->k + 1 || !d_recs) return fail(KQ_ERR_CAPACITY, "record buffer too small: need room for %llu records",
                                                        (unsigned long long)(len - h->k + 1));
     const uint8_t* ab; uint64_t lead;

@@ -132,13 +132,23 @@ class BatchQueue {                       // bounded multi-producer / single-cons
     size_t cap_;
     unsigned producers_;
     std::string error_;
+    bool cancelled_ = false;
 public:
     BatchQueue(size_t cap, unsigned producers) : cap_(cap), producers_(producers) {}
-    void push(std::string&& b) {
+    // false: the consumer gave up (its callback threw); the producer must stop
+    bool push(std::string&& b) {
         std::unique_lock<std::mutex> l(m_);
-        not_full_.wait(l, [&] { return q_.size() < cap_; });
+        not_full_.wait(l, [&] { return q_.size() < cap_ || cancelled_; });
+        if (cancelled_) return false;
         q_.push_back(std::move(b));
         not_empty_.notify_one();
+        return true;
+    }
+    void cancel() {
+        std::lock_guard<std::mutex> l(m_);
+        cancelled_ = true;
+        q_.clear();
+        not_full_.notify_all();
     }
     void producer_done(const std::string& err = std::string()) {
         std::lock_guard<std::mutex> l(m_);
@@ -211,11 +221,13 @@ void read_batches_parallel(const std::string& path, size_t batch_bytes, unsigned
         if (fd >= 0) close(fd);
         BatchQueue q(4, 1);
         std::thread prod([&] {
-            try { read_batches(path, batch_bytes, [&](const std::string& b) { q.push(std::string(b)); }); q.producer_done(); }
-            catch (const std::exception& e) { q.producer_done(e.what()); }
+            try {
+                read_batches(path, batch_bytes, [&](const std::string& b) { if (!q.push(std::string(b))) throw std::runtime_error("cancelled"); });
+                q.producer_done();
+            } catch (const std::exception& e) { q.producer_done(e.what()); }
         });
         std::string b;
-        try { while (q.pop(b)) on_batch(b); } catch (...) { prod.join(); throw; }
+        try { while (q.pop(b)) on_batch(b); } catch (...) { q.cancel(); prod.join(); throw; }
         prod.join();
         return;
     }
@@ -238,11 +250,16 @@ void read_batches_parallel(const std::string& path, size_t batch_bytes, unsigned
                 const char* lo = begin + c * chunk;
                 const char* hi = std::min(end, lo + chunk);
                 const char* p = fastq ? fastq_sync(lo, begin, end) : fasta_sync(lo, begin, end);
+                if (c == 0 && p != begin) throw std::runtime_error("malformed " + std::string(fastq ? "FASTQ" : "FASTA") + " record at the start of " + path);
                 while (p < hi) {                          // records whose header starts inside [lo, hi)
                     if (fastq) {
                         const char* seq = next_line(p, end);
                         const char* plus = next_line(seq, end);
                         const char* qual = next_line(plus, end);
+                        // four-line records only, like the reference's loader (src/input.cpp:245-286): anything else
+                        // (wrapped sequence / quality lines) is refused instead of being mis-parsed silently
+                        if (*p != '@' || (plus < end && *plus != '+'))
+                            throw std::runtime_error("malformed FASTQ record (four-line records expected) at byte " + std::to_string((size_t)(p - begin)) + " of " + path);
                         append_seq(batch, seq, plus);
                         p = next_line(qual, end);
                     } else {
@@ -259,7 +276,16 @@ void read_batches_parallel(const std::string& path, size_t batch_bytes, unsigned
                         }
                         p = nxt;
                     }
-                    if (batch.size() >= batch_bytes) { q.push(std::move(batch)); batch.clear(); batch.reserve(batch_bytes + (1 << 16)); }
+                    // the records of a chunk must end where the next chunk finds its first one: anything else means the
+                    // resynchronisation and the parser disagree about the record structure (wrapped FASTQ lines ...)
+                    if (p >= hi && hi < end) {
+                        const char* want = fastq ? fastq_sync(hi, begin, end) : fasta_sync(hi, begin, end);
+                        if (p != want) throw std::runtime_error("malformed " + std::string(fastq ? "FASTQ (four-line records expected)" : "FASTA") + " near byte " + std::to_string((size_t)(hi - begin)) + " of " + path);
+                    }
+                    if (batch.size() >= batch_bytes) {
+                        if (!q.push(std::move(batch))) { q.producer_done(); return; }
+                        batch.clear(); batch.reserve(batch_bytes + (1 << 16));
+                    }
                 }
             }
             if (!batch.empty()) q.push(std::move(batch));
@@ -270,7 +296,12 @@ void read_batches_parallel(const std::string& path, size_t batch_bytes, unsigned
     for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker);
     std::string b;
     try { while (q.pop(b)) on_batch(b); }
-    catch (...) { for (auto& t : pool) t.detach(); munmap((void*)data, size); close(fd); throw; }
+    catch (...) {                                  // workers still read the mapping: stop them, join, only then unmap
+        q.cancel();
+        for (auto& t : pool) t.join();
+        munmap((void*)data, size); close(fd);
+        throw;
+    }
     for (auto& t : pool) t.join();
     munmap((void*)data, size);
     close(fd);

@@ -468,8 +468,10 @@ int main(int argc, char** argv) {
             if (argc >= 4 && std::string(argv[2]) == "seqsum") {       // order-independent digest of the sequences a reader yields
                 const unsigned threads = argc > 4 ? (unsigned)atoi(argv[4]) : 0;
                 const size_t batch = argc > 5 ? (size_t)atoll(argv[5]) : ((size_t)1 << 20);
-                unsigned long long n = 0, bases = 0, digest = 0;
+                unsigned long long n = 0, bases = 0, digest = 0, batches = 0;
+                const char* fail_after = getenv("KQ_TEST_FAIL_AFTER_BATCHES");     // failure-path test: the consumer throws mid-file
                 auto eat = [&](const std::string& b) {
+                    if (fail_after && ++batches > (unsigned long long)atoll(fail_after)) throw std::runtime_error("consumer failed (injected)");
                     size_t i = 0;
                     while (i <= b.size()) {
                         size_t j = b.find('\n', i);

@@ -88,3 +88,32 @@ def test_golden_inputs_all_readers(cli):
         want = py_digest([s for _, s in H.read_fastx(H.golden_input(name))])
         assert seqsum(cli, H.golden_input(name), 0) == want, name
         assert seqsum(cli, H.golden_input(name), 4) == want, name
+
+
+def test_wrapped_fastq_is_refused(cli, tmp_path):
+    """four-line FASTQ only (like the reference's loader): a wrapped record must fail loudly, not be mis-parsed"""
+    p = str(tmp_path / "wrapped.fastq")
+    with open(p, "wb") as f:
+        for i in range(2000):
+            f.write(b"@r%d\nACGTACGTAC\nGTACGTACGT\n+\nIIIIIIIIII\nIIIIIIIIII\n" % i)
+    r = subprocess.run([cli, "dbtool", "seqsum", p, "4", "4096"], capture_output=True, text=True)
+    assert r.returncode != 0 and "malformed FASTQ" in r.stderr
+
+
+def test_consumer_failure_stops_the_parser_threads(cli, tmp_path):
+    """when the batch consumer throws, the parser threads are cancelled and joined before the file mapping
+    goes away (was: detached threads reading an unmapped file)"""
+    import os
+
+    p = str(tmp_path / "reads.fastq")
+    make_fastq(p, 60000, seed=3, nasty_quals=False)
+    for threads in (4, 8):
+        r = subprocess.run([cli, "dbtool", "seqsum", p, str(threads), "65536"], capture_output=True, text=True,
+                           env=dict(os.environ, KQ_TEST_FAIL_AFTER_BATCHES="3"), timeout=60)
+        assert r.returncode == 1 and "consumer failed" in r.stderr, (r.returncode, r.stderr)
+    gz = p + ".gz"
+    with open(p, "rb") as src, gzip.open(gz, "wb", compresslevel=1) as dst:
+        dst.write(src.read())
+    r = subprocess.run([cli, "dbtool", "seqsum", gz, "4", "65536"], capture_output=True, text=True,
+                       env=dict(os.environ, KQ_TEST_FAIL_AFTER_BATCHES="3"), timeout=60)
+    assert r.returncode == 1 and "consumer failed" in r.stderr
