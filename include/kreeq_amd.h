@@ -205,6 +205,20 @@ int  kq_lookup_sequence_dev(kq_handle* h, const char* d_bases, uint64_t len, uin
                             uint16_t map_lo, uint16_t map_hi, kq_dbgbase* d_per_base,
                             uint64_t* d_counters);
 
+/* ---- candidate-error search support (DBG::correctSequences, src/variants.cpp) --------------------------------- */
+
+/* Batched map->find(key) (src/variants.cpp:118-131, :203-206; src/kreeq.cpp:152-166 for the 32-bit tier): the logical
+ * entries of n canonical keys, out[i].key = keys[i]; out[i].cov == 0 when the k-mer is absent.  The bounded graph
+ * search stays on the host (pointer chasing, serial per source); it asks for its frontier in batches through this. */
+int  kq_lookup_keys(kq_handle* h, const uint64_t* keys, uint64_t n, kq_entry* out);
+
+/* Device pre-filter of the search: for every k-mer start c of `bases` (segments = ACGT runs, like kq_lookup_sequence),
+ * flags[c] bit 0 = the k-mer is in the table, bit 1 = DBG::searchVariants would find at least one candidate path at
+ * its source (src/variants.cpp:232-246 at depth 0): an edge in the direction the sequence is read, with a count
+ * above cov_cutoff, that does not lead to the k-mer the sequence continues with.  Only those positions need the host
+ * search; everywhere else it returns at once without a variant.  flags has `len` bytes (0 where no k-mer starts). */
+int  kq_branch_scan(kq_handle* h, const char* bases, uint64_t len, uint32_t cov_cutoff, uint8_t* flags);
+
 /* ---- union / database import-export --------------------------------------------------------- */
 
 /* Replaces DBG::kunion + DBG::mergeSubMaps (src/graph-builder.cpp:297-432): dst += src, exact

@@ -15,7 +15,7 @@ DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw",
 SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_get_profile", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_flush", "kq_get_info", "kq_last_error",
            "kq_abi_version", "kq_device_available", "kq_device_memory", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
            "kq_emit_partitioned_dev", "kq_emit_packed_dev", "kq_insert_packed_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
-           "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_merge", "kq_import", "kq_export"]
+           "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_lookup_keys", "kq_branch_scan", "kq_merge", "kq_import", "kq_export"]
 
 
 class KqError(RuntimeError):
@@ -102,6 +102,8 @@ def load():
     L.kq_histogram.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.kq_lookup_sequence.argtypes = [vp, vp, u64, u32, u16, u16, vp, vp]
     L.kq_lookup_sequence_dev.argtypes = [vp, vp, u64, u32, u16, u16, vp, vp]
+    L.kq_lookup_keys.argtypes = [vp, vp, u64, vp]
+    L.kq_branch_scan.argtypes = [vp, vp, u64, u32, vp]
     L.kq_merge.argtypes = [vp, vp]
     L.kq_import.argtypes = [vp, vp, u64]
     L.kq_export.argtypes = [vp, u16, u16, vp, u64, C.POINTER(u64)]
@@ -252,6 +254,18 @@ class KreeqDB:
             map_hi = self.map_count
         _check(load().kq_lookup_sequence_dev(self._h, C.c_void_p(bases_ptr), n, cov_cutoff, map_lo, map_hi,
                                              C.c_void_p(per_base_ptr) if per_base_ptr else None, C.c_void_p(counters_ptr)))
+
+    def lookup_keys(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(len(keys), dtype=ENTRY_DTYPE)
+        _check(load().kq_lookup_keys(self._h, _p(keys), len(keys), _p(out)))
+        return out
+
+    def branch_scan(self, bases: bytes, cov_cutoff=0):
+        buf = np.frombuffer(bases, dtype=np.uint8)
+        flags = np.zeros(len(buf), dtype=np.uint8)
+        _check(load().kq_branch_scan(self._h, _p(buf), len(buf), cov_cutoff, _p(flags)))
+        return flags
 
     # -- union / io
     def merge(self, other):

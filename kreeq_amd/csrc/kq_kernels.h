@@ -1428,6 +1428,53 @@ __global__ __launch_bounds__(TILE_THREADS) void k_lookup(TableView t, const uint
     }
 }
 
+// map->find(key) for a batch of canonical keys (candidate-error search, src/variants.cpp:118-131, :203-206)
+__global__ __launch_bounds__(256) void k_lookup_keys(TableView t, const uint64_t* __restrict__ keys, uint64_t n, kq_entry* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i];
+        kq_entry e;
+        e.key = key; e.cov = 0; e.hc = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { e.fw[w] = 0; e.bw[w] = 0; }
+        const uint64_t space_ok = t.k == 32 ? 1 : (key >> (2 * t.k)) == 0;
+        if (space_ok) {
+            const uint64_t h = table_hash(key, t.k);
+            const Slot* s = table_find(t, h);
+            if (s) {
+                const Logical L = logical_of(t, h, s->w0, s->e8);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { e.fw[w] = L.e[w]; e.bw[w] = L.e[4 + w]; }
+                e.cov = L.cov; e.hc = L.cov > LOW_TIER_MAX;
+            }
+        }
+        out[i] = e;
+    }
+}
+// pre-filter of the candidate-error search: see kq_branch_scan (include/kreeq_amd.h)
+__global__ __launch_bounds__(TILE_THREADS) void k_branch_scan(TableView t, const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k,
+                                                               uint32_t cov_cutoff, uint8_t* __restrict__ flags) {
+    scan_tiles(ab, lead, len, k, [&](uint64_t pos, uint64_t fw, uint64_t rv, uint32_t, uint32_t next) {
+        const bool is_fw = fw < rv;
+        const uint64_t h = table_hash(is_fw ? fw : rv, (uint32_t)k);
+        const Slot* s = table_find(t, h);
+        uint8_t f = 0;
+        if (s) {
+            f = 1;
+            const Logical L = logical_of(t, h, s->w0, s->e8);
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                // direction = isSourceFw; `direction ? fw[i] : bw[i] > covCutOff` (src/variants.cpp:237); the candidate
+                // continues the sequence with base i (fw) or 3 - i (bw of the reverse strand): it is the reference
+                // path (:241) iff that base is the one the sequence has next
+                const bool edge = is_fw ? (L.e[i] != 0) : (L.e[4 + i] > cov_cutoff);
+                const uint32_t base = is_fw ? i : 3u - i;
+                if (edge && base != next) f |= 2;
+            }
+        }
+        flags[pos] = f;
+    });
+}
+
 // export ordering: keys / indices of the compacted entries, then the entries gathered in key order
 __global__ __launch_bounds__(256) void k_entry_keys(const kq_entry* __restrict__ e, uint64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { keys[i] = e[i].key; idx[i] = (uint32_t)i; }

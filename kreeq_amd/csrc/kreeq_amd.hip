@@ -1276,6 +1276,50 @@ int kq_lookup_sequence(kq_handle* h, const char* bases, uint64_t len, uint32_t c
     return rc;
 }
 
+// ---- candidate-error search support ---------------------------------------------------------------
+int kq_lookup_keys(kq_handle* h, const uint64_t* keys, uint64_t n, kq_entry* out) {
+    if (!h || ((!keys || !out) && n)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    if (!n) return KQ_OK;
+    int rc = flush_pending(h);
+    if (rc) return rc;
+    materialize(h);
+    // keys in, entries out: one scratch buffer (8 + 48 bytes per key)
+    rc = ensure_buf(&h->stage, &h->stage_bytes, (size_t)n * (sizeof(uint64_t) + sizeof(kq_entry)) + 64);
+    if (rc) return rc;
+    uint64_t* d_keys = (uint64_t*)h->stage;
+    kq_entry* d_out = (kq_entry*)(d_keys + ((n + 1) & ~1ull));
+    HIPC(hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_lookup_keys, dim3(grid_for(h, n, 256)), dim3(256), 0, h->stream, h->view(), d_keys, n, d_out);
+    HIPC(hipMemcpyAsync(out, d_out, n * sizeof(kq_entry), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    return KQ_OK;
+}
+int kq_branch_scan(kq_handle* h, const char* bases, uint64_t len, uint32_t cov_cutoff, uint8_t* flags) {
+    if (!h || ((!bases || !flags) && len)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    if (len) memset(flags, 0, len);
+    if (len < (uint64_t)h->k) return KQ_OK;
+    int rc = flush_pending(h);
+    if (rc) return rc;
+    materialize(h);
+    void* d = nullptr;
+    rc = stage_in(h, bases, len, &d);
+    if (rc) return rc;
+    uint8_t* d_flags = nullptr;
+    HIPC(hipMalloc((void**)&d_flags, len));
+    (void)hipMemsetAsync(d_flags, 0, len, h->stream);
+    const uint8_t* ab; uint64_t lead;
+    aligned_view((const char*)d, &ab, &lead);
+    hipLaunchKernelGGL(k_branch_scan, dim3(grid_for(h, n_tiles_of(lead, len), 1, 32)), dim3(TILE_THREADS), 0, h->stream, h->view(), ab, lead, len, h->k,
+                       cov_cutoff, d_flags);
+    hipError_t e1 = hipMemcpyAsync(flags, d_flags, len, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_flags);
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(KQ_ERR_HIP, "branch scan failed: %s", hipGetErrorString(e2 != hipSuccess ? e2 : e1));
+    return KQ_OK;
+}
+
 // ---- union / import / export ---------------------------------------------------------------------
 int kq_merge(kq_handle* dst, kq_handle* src) {
     if (!dst || !src) return fail(KQ_ERR_INVALID, "null handle");

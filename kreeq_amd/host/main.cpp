@@ -22,6 +22,7 @@
 #include "fastx.h"
 #include "kreeq_amd.h"
 #include "kreeq_db.h"
+#include "variants.h"
 
 using namespace kqhost;
 
@@ -240,6 +241,17 @@ struct Engine {
             }
         }
     }
+    // -o vcf / -o x.vcf: DBG::correctSequences (src/variants.cpp:40-50) + gfalibs' VCF writer; "-o vcf" names no file:
+    // the records go to stdout (validateFiles/test.50.tst)
+    void write_vcf() {
+        if (ui.inSequence.empty()) return;                           // src/variants.cpp:42-43
+        const int depth = ui.kmerDepth == -1 ? k : ui.kmerDepth;     // include/kreeq.h:171-173 (unidirectional search)
+        auto sites = find_candidate_errors(h, k, genome.seqs, depth, ui.maxSpan, ui.covCutOff, [](const std::string& m) { verbose(m); });
+        auto lines = vcf_lines(genome.seqs, sites);
+        if (ui.outFile == "vcf") { for (auto& l : lines) std::cout << l << "\n"; return; }
+        std::ofstream ofs(ui.outFile);
+        for (auto& l : lines) ofs << l << "\n";
+    }
     void write_hist(const std::string& path) {                       // gfalibs printHist (format not pinned by any fixture)
         uint64_t n = 0;
         kq_or_die(kq_histogram(h, nullptr, nullptr, 0, &n));
@@ -255,8 +267,9 @@ struct Engine {
         if (ui.outFile.find(".") != std::string::npos || ui.outFile == "" || ext == "kreeq") { stats(); verbose("Summary computed"); }
         verbose("Writing ouput: " + ui.outFile);
         const bool per_base_out = (ext == "kwig" || ext == "bkwig" || ext == "bed" || ext == "csvtable");
-        if (ext == "gfa" || ext == "gfa2" || ext == "gfa.gz" || ext == "gfa2.gz" || ext == "vcf")
-            die("Error: ." + ext + " output (variant search) is not supported by this build");
+        if (ext == "gfa" || ext == "gfa2" || ext == "gfa.gz" || ext == "gfa2.gz")
+            die("Error: ." + ext + " output (variant graph) is not supported by this build: use -o vcf");
+        if (ext == "vcf") { if (ui.mode == 0) write_vcf(); return; }   // case 6: correctSequences, then printVCF (src/kreeq-output.cpp:74-82, :124-127)
         // the reference's first switch has no case for .kreeq / .hist, so they fall to `default:` like every other
         // extension and validate too (src/kreeq-output.cpp:62-72); validateSequences returns at once without -f
         if (ui.mode == 0) validate_sequences(per_base_out);
@@ -312,7 +325,7 @@ int run_passes(Engine& e) {
     std::string ext = "stdout";
     if (ui.outFile != "") ext = file_ext("." + ui.outFile);
     if (ext == "gfa" || ext == "gfa2" || ext == "gfa.gz" || ext == "gfa2.gz" || ext == "vcf")
-        die("Error: ." + ext + " output (variant search) is not supported by this build");
+        die("Error: ." + ext + " output (variant search) needs the whole table resident: it cannot run in map-range passes (raise -m / lower --passes)");
     if (!ui.inSequence.empty()) load_genome(ui.inSequence, e.genome);
     const bool want_stats = ui.outFile.find(".") != std::string::npos || ui.outFile == "" || ext == "kreeq";
     const bool want_validate = !ui.inSequence.empty();              // every extension validates (src/kreeq-output.cpp:62-72)

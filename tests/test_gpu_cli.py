@@ -229,3 +229,62 @@ def test_union_of_three_goes_through_merge(cli, tmp_path, golden_dbs):
     out_w = run(cli, ["validate", "-r"] + [H.golden_input(n) for n in ("random1.fastq", "random2.fastq", "random3.N.fastq")] + ["-o", whole])
     assert [l for l in out_u if l] == [l for l in out_w if l]
     assert decode_db(u) == decode_db(whole)
+
+
+def test_vcf_golden_replay(cli):
+    """validateFiles/test.50.tst through the CLI (-o vcf --search-depth 50 --max-span 32): device pre-filter + host search
+    with batched device lookups; 30 of 31 records line for line (the 31st: helpers.VCF_GOLDEN_DEVIATION)"""
+    argv, expected = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.50.tst"))
+    got = run(cli, remap(argv, None))
+    while got and got[-1] == "":
+        got.pop()
+    assert got == H.vcf_expected(expected)
+
+
+def test_vcf_random_vs_oracle(cli, tmp_path):
+    """a 30 kb genome with planted substitutions, insertions and deletions (some close together), error-free reads at 12x:
+    the CLI's VCF (GPU table, device pre-filter, lockstep host searches) equals the Python restatement's on the oracle table"""
+    import numpy as np
+
+    from oracle import oracle as O
+    from oracle import variants as V
+
+    rng = np.random.default_rng(7)
+    acgt = "ACGT"
+    genome = "".join(acgt[i] for i in rng.integers(0, 4, 30000))
+    reads = []
+    for s in rng.integers(0, len(genome) - 150, 2400):
+        r = genome[s:s + 150]
+        if rng.random() < 0.5:
+            r = r[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        reads.append(r)
+    asm = list(genome)
+    for p in sorted(rng.choice(np.arange(200, len(genome) - 200), 60, replace=False), reverse=True):
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            asm[p] = acgt[(acgt.index(asm[p]) + 1 + rng.integers(0, 3)) % 4].lower()
+        elif kind == 1:
+            del asm[p]
+        else:
+            asm.insert(p, acgt[rng.integers(0, 4)].lower())
+    asm = "".join(asm)
+    recs = [("chrA", asm[:14000]), ("chrB", asm[14000:20000] + "NNNN" + asm[20000:])]
+    fa, fq = str(tmp_path / "asm.fasta"), str(tmp_path / "reads.fastq")
+    with open(fa, "w") as f:
+        for h, s in recs:
+            f.write(f">{h}\n{s}\n")
+    with open(fq, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+    got = run(cli, ["validate", "-f", fa, "-r", fq, "-o", "vcf", "--search-depth", "60", "--max-span", "20"])
+    while got and got[-1] == "":
+        got.pop()
+    db = O.OracleDB(21, 128)
+    db.count_batch("\n".join(reads).encode(), threads=4)
+    want = V.correct_sequences(V.Graph(db.export(), 21), recs, 60, 20)
+    assert len(want) > 4 + 30
+    assert got == want
+    out = str(tmp_path / "calls.vcf")                                  # a named file instead of stdout; stats are printed then ('.' in the name)
+    stdout = run(cli, ["validate", "-f", fa, "-r", fq, "-o", out, "--search-depth", "60", "--max-span", "20"])
+    assert open(out).read().split("\n")[:-1] == want
+    assert stdout[0] == "DBG Summary statistics:"

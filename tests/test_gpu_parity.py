@@ -748,3 +748,50 @@ def test_partitioned_paths_degenerate_inputs(kq, O):
     c, _ = empty.lookup_sequence(genome)
     cc, _ = cpu.validate_sequence(genome, threads=8)
     assert np.array_equal(c, cc)
+
+
+def test_lookup_keys_and_branch_scan(kq, O):
+    """kq_lookup_keys == map->find per key (present and absent keys, a high-copy k-mer included); kq_branch_scan flags
+    = (present, searchVariants has a candidate at depth 0) per position, checked against the oracle's table"""
+    from oracle import variants as V
+
+    k = 21
+    batch, genome = H.synth_reads(3000, 150, 40000, seed=61, err=0.01)
+    hot = b"\n".join([b"ACGTTGCA" * 19] * 300)
+    gpu, cpu = kq.KreeqDB(k, 128), O.OracleDB(k, 128)
+    for b in (batch, hot):
+        gpu.count_batch(b)
+        cpu.count_batch(b, threads=4)
+    want = cpu.export()
+    rng = np.random.default_rng(3)
+    absent = rng.integers(0, 1 << 42, 500, dtype=np.uint64)
+    absent = absent[~np.isin(absent, want["key"])]
+    keys = np.concatenate([want["key"], absent])
+    perm = rng.permutation(len(keys))
+    got = gpu.lookup_keys(keys[perm])
+    inv = np.argsort(perm)
+    got = got[inv]
+    assert H.entries_equal(got[:len(want)], want)
+    assert want["cov"].max() > 255
+    assert (got[len(want):]["cov"] == 0).all() and (got[len(want):]["key"] == absent).all()
+    # branch scan over the genome (lower-case bases and an N included)
+    seq = bytearray(genome[:20000])
+    seq[5000] = ord("N")
+    seq = bytes(seq)
+    flags = gpu.branch_scan(seq)
+    g = V.Graph(want, k)
+    codes = [V.CTOI.get(chr(c), 4) for c in seq]
+    for c in range(len(seq)):
+        window = codes[c:c + k]
+        f = 0
+        if len(window) == k and 4 not in window:
+            key, fw = V.hash_kmer(window, k)
+            if key in g.nodes:
+                f = 1
+                nxt = codes[c + k] if c + k < len(seq) else 4
+                fwc, bwc, _ = g.nodes[key]
+                for i in range(4):
+                    edge = fwc[i] != 0 if fw else bwc[i] > 0
+                    if edge and (i if fw else 3 - i) != nxt:
+                        f |= 2
+        assert flags[c] == f, (c, flags[c], f)

@@ -144,3 +144,19 @@ def test_overflow_invariant():
         k8, v8 = db.export_raw8(3)
         tomb = {int(k) for k, v in zip(k8, v8) if v["cov"] == 255}
         assert tomb == {kk for kk, v in exp.items() if v[8] >= 255 and kk % 128 == 3}
+
+
+def test_vcf_golden():
+    """candidate-error search (oracle/variants.py, src/variants.cpp) against validateFiles/test.50.tst: 30 of its 31
+    records line for line; the 31st is the documented deviation of helpers.VCF_GOLDEN_DEVIATION"""
+    from oracle import variants as V
+
+    argv, expected = H.parse_tst(os.path.join(H.GOLDEN, "validateFiles", "test.50.tst"))
+    assert argv[-4:] == ["--search-depth", "50", "--max-span", "32"]
+    db = O.OracleDB(21, 128)
+    db.count_batch(H.reads_batch([H.golden_input("to_correct.fastq")]))
+    g = V.Graph(db.export(), 21)
+    recs = [(h, s.decode()) for h, s in H.read_fastx(H.golden_input("to_correct.fasta"))]
+    got = V.correct_sequences(g, recs, 50, 32)
+    assert got == H.vcf_expected(expected)
+    assert sum(a != b for a, b in zip(got, expected)) == 1 and len(got) == len(expected) == 35
