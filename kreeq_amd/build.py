@@ -11,6 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "lib", "libkreeq_amd.so")
 CLI = os.path.join(PKG, "bin", "kreeq")
+HOSTLIB = os.path.join(PKG, "lib", "libkreeq_host.so")       # .kreeq database files for the multi-GPU driver (no GPU code)
 
 HIP_SOURCES = [os.path.join(PKG, "csrc", "kreeq_amd.hip")]
 HIP_DEPS = HIP_SOURCES + [os.path.join(PKG, "csrc", f) for f in ("kq_device.h", "kq_partition.h", "kq_kernels.h")] + [os.path.join(ROOT, "include", "kreeq_amd.h")]
@@ -47,7 +48,19 @@ def build_lib(force=False, verbose=False, out=None, defines=()):
 def host_sources():
     if not os.path.isdir(HOST_DIR):
         return []
-    return sorted(os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith(".cpp"))
+    return sorted(os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith(".cpp") and f != "hostlib.cpp")
+
+
+def build_hostlib(force=False, verbose=False):
+    srcs = [os.path.join(HOST_DIR, f) for f in ("hostlib.cpp", "kreeq_db.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, "kreeq_db.h"), os.path.join(ROOT, "include", "kreeq_amd.h")]
+    if force or _stale(HOSTLIB, deps):
+        os.makedirs(os.path.dirname(HOSTLIB), exist_ok=True)
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-fPIC", "-shared", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", HOSTLIB] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOSTLIB
 
 
 def build_cli(force=False, verbose=False):
@@ -68,3 +81,4 @@ def build_cli(force=False, verbose=False):
 def build_all(force=False, verbose=False):
     build_lib(force, verbose)
     build_cli(force, verbose)
+    build_hostlib(force, verbose)

@@ -84,6 +84,13 @@ class GpuEngine:
         s = self.db.summary()
         return torch.tensor([s["total"], s["unique"], s["distinct"], s["edges"]], dtype=torch.int64, device=self.device)
 
+    def histogram(self):
+        """{cov: count} of this rank's k-mers (finalHistogram, src/graph-builder.cpp:274-278)"""
+        return self.db.summary(with_hist=True)["hist"]
+
+    def export(self, map_lo, map_hi):
+        return self.db.export(map_lo, map_hi)
+
     def sync(self):
         self.db.sync()
 
@@ -101,6 +108,7 @@ class ShardedCounter:
         self.sharded_path = sharded_path
         self.force_exchange = False
         self.n_chunks = int(os.environ.get("KQ_EXCHANGE_CHUNKS", "2"))   # pipeline depth of the exchange
+        self._recv = {}
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if self.world > map_count:
@@ -135,17 +143,27 @@ class ShardedCounter:
         cuts.append(n)
         return list(zip(cuts[:-1], cuts[1:]))
 
-    def _exchange_start(self, payload, send_counts):
-        """counts first (blocking, tiny), then one asynchronous all-to-all(v) per payload array"""
+    def _recv_buffer(self, slot, j, n, like):
+        """persistent receive arrays (two slots: chunk i is received while chunk i-1 is inserted), grown geometrically"""
+        key = (slot, j)
+        buf = self._recv.get(key)
+        if buf is None or buf.numel() < n or buf.dtype != like.dtype:
+            buf = torch.empty(max(n + n // 8, 1), dtype=like.dtype, device=like.device)
+            self._recv[key] = buf
+        return buf[:n]
+
+    def _exchange_start(self, payload, send_counts, slot=0):
+        """counts first (tiny; its result is needed on the host because all_to_all_single takes host split sizes), then
+        one asynchronous all-to-all(v) per payload array into persistent receive buffers"""
         dev = payload[0].device
-        sc = torch.from_numpy(send_counts).to(dev)
+        sc = torch.from_numpy(send_counts).to(dev, non_blocking=True)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)                 # how many records each peer sends me
         recv_counts = rc.cpu().numpy()
         n_recv = int(recv_counts.sum())
         received, works = [], []
-        for t in payload:
-            r = torch.empty(n_recv, dtype=t.dtype, device=dev)
+        for j, t in enumerate(payload):
+            r = self._recv_buffer(slot, j, n_recv, t)
             works.append(dist.all_to_all_single(r, t, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
                                                 group=self.group, async_op=True))
             received.append(r)
@@ -166,7 +184,7 @@ class ShardedCounter:
         for i, (lo, hi) in enumerate(chunks):
             # send buffer i % 2: the exchange of chunk i-2 was waited for before chunk i-1 was started
             payload, send_counts = self.engine.emit_partitioned(bases[lo:hi], self.world, slot=i % 2)
-            started = self._exchange_start(payload, send_counts)
+            started = self._exchange_start(payload, send_counts, slot=i % 2)
             if pending is not None:
                 received, works, _ = pending
                 for w in works:
@@ -188,6 +206,51 @@ class ShardedCounter:
             if self.world > 1:
                 dist.all_reduce(ctr, op=dist.ReduceOp.SUM, group=self.group)
             return ctr.cpu().numpy().astype(np.uint64)
+
+    HIST_DENSE = 4096        # coverages below this travel as one dense all-reduce; the few above are gathered as pairs
+
+    def histogram(self):
+        """the coverage histogram of the whole database {cov: count}: all-reduce(sum) of the per-rank histograms
+        (the shards hold disjoint k-mers): the all-reduce for the final histogram that BASELINE.json's north_star names"""
+        with self._stream_ctx():
+            local = self.engine.histogram()
+            if self.world == 1:
+                return dict(sorted(local.items()))
+            dev = getattr(self.engine, "device", torch.device("cpu"))
+            dense = torch.zeros(self.HIST_DENSE, dtype=torch.int64, device=dev)
+            small = [(c, n) for c, n in local.items() if c < self.HIST_DENSE]
+            if small:
+                idx = torch.tensor([c for c, _ in small], dtype=torch.int64, device=dev)
+                dense[idx] = torch.tensor([n for _, n in small], dtype=torch.int64, device=dev)
+            dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=self.group)
+            big = [(c, n) for c, n in local.items() if c >= self.HIST_DENSE]
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, big, group=self.group)
+            out = {int(c): int(n) for c, n in enumerate(dense.cpu().tolist()) if n}
+            for part in gathered:
+                for c, n in part:
+                    out[int(c)] = out.get(int(c), 0) + int(n)
+            return dict(sorted(out.items()))
+
+    def export_db(self, db_dir):
+        """ONE .kreeq database from the shards: every rank writes the map files it owns (.map.<m>.bin, m in its
+        range), the high-copy k-mers are gathered on rank 0, which writes .map.hc.bin and .index -- the reference's HPC
+        flow (separate databases, then `union`; README.md:31-39) without the union: the shards are bucket-disjoint.
+        All ranks must see the same directory (one node)."""
+        from . import hostdb
+
+        ent = self.engine.export(self.map_lo, self.map_hi)
+        hc = hostdb.write_maps(db_dir, self.map_count, self.map_lo, self.map_hi, ent)
+        if self.world > 1:
+            gathered = [None] * self.world if self.rank == 0 else None
+            dist.gather_object(hc, gathered, dst=0, group=self.group)
+            if self.rank == 0:
+                hc = np.concatenate(gathered) if gathered else hc
+        if self.rank == 0:
+            hostdb.write_finish(db_dir, self.k, self.map_count, hc)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        return len(ent)
 
     def summary(self):
         with self._stream_ctx():

@@ -41,6 +41,14 @@ class HostEngine:
         s = self.db.summary()
         return torch.tensor([s["total"], s["unique"], s["distinct"], s["edges"]], dtype=torch.int64)
 
+    def histogram(self):
+        return self.db.summary(with_hist=True)["hist"]
+
+    def export(self, map_lo, map_hi):
+        ent = self.db.export()
+        m = ent["key"] % np.uint64(self.map_count)
+        return ent[(m >= map_lo) & (m < map_hi)]
+
 
 def _free_port():
     with socket.socket() as s:
@@ -65,11 +73,15 @@ def _worker(rank, world, port, k, out_dir):
         _, genome = H.synth_reads(10, 100, 30000, seed=1000)          # same genome (seed of rank 0, batch 0)
         ctr = sc.validate(torch.frombuffer(bytearray(genome), dtype=torch.uint8))
         summ = sc.summary()
+        hist = sc.histogram()
+        n_written = sc.export_db(os.path.join(out_dir, "sharded.kreeq"))
         ent = sc.engine.db.export()
+        assert n_written == len(ent)
         m = ent["key"] % 128
         assert np.all((m >= sc.map_lo) & (m < sc.map_hi))                # a rank holds only the maps it owns
         np.save(os.path.join(out_dir, f"entries_{rank}.npy"), ent)
         if rank == 0:
+            np.save(os.path.join(out_dir, "hist.npy"), np.array(sorted(hist.items()), dtype=np.uint64))
             np.save(os.path.join(out_dir, "ctr.npy"), ctr)
             np.save(os.path.join(out_dir, "summ.npy"), np.array([summ[f] for f in ("total", "unique", "distinct", "missing", "edges")], dtype=np.uint64))
     finally:
@@ -94,8 +106,23 @@ def test_sharded_count_matches_single(tmp_path, world, k):
     assert H.entries_equal(merged, ref.export())
     c, _ = ref.validate_sequence(genome)
     assert np.load(os.path.join(tmp_path, "ctr.npy")).tolist() == c.tolist()
-    s = ref.summary()
+    s = ref.summary(with_hist=True)
     assert np.load(os.path.join(tmp_path, "summ.npy")).tolist() == [s[f] for f in ("total", "unique", "distinct", "missing", "edges")]
+    # the all-reduced coverage histogram is the single-process one
+    assert [tuple(x) for x in np.load(os.path.join(tmp_path, "hist.npy")).tolist()] == sorted(s["hist"].items())
+    # the ranks together wrote ONE database: identical content to a single-process one (read back with the host reader)
+    from kreeq_amd import hostdb
+
+    got, gk, gm = hostdb.read_db(os.path.join(tmp_path, "sharded.kreeq"))
+    assert (gk, gm) == (k, 128)
+    assert H.entries_equal(got, ref.export())
+    single = os.path.join(tmp_path, "single.kreeq")
+    e = ref.export()
+    hc = hostdb.write_maps(single, 128, 0, 128, e)
+    hostdb.write_finish(single, k, 128, hc)
+    for name in [".index", ".map.hc.bin"] + [f".map.{m}.bin" for m in range(128)]:
+        a, b = os.path.join(tmp_path, "sharded.kreeq", name), os.path.join(single, name)
+        assert os.path.getsize(a) == os.path.getsize(b), name
 
 
 def test_owner_mapping_is_a_partition():

@@ -429,6 +429,17 @@ def test_sharded_counter_single_rank(kq, O):
     ctr = sc.validate(torch.frombuffer(bytearray(genome), dtype=torch.uint8).cuda())
     cc, _ = cpu.validate_sequence(genome)
     assert ctr.tolist() == cc.tolist()
+    # coverage histogram and the database written from the shard(s)
+    import tempfile
+
+    from kreeq_amd import hostdb
+
+    assert sc.histogram() == dict(sorted(cpu.summary(with_hist=True)["hist"].items()))
+    with tempfile.TemporaryDirectory() as d:
+        db = os.path.join(d, "shards.kreeq")
+        assert sc.export_db(db) == cpu.summary()["distinct"]
+        got, gk, gm = hostdb.read_db(db)
+        assert (gk, gm) == (21, 128) and H.entries_equal(got, cpu.export())
 
 
 def test_sharded_counter_rccl_world1(kq, O):
@@ -459,6 +470,7 @@ def test_sharded_counter_rccl_world1(kq, O):
         ctr = sc.validate(torch.frombuffer(bytearray(genome), dtype=torch.uint8).cuda())
         cc, _ = cpu.validate_sequence(genome)
         assert ctr.tolist() == cc.tolist()
+        assert sc.histogram() == dict(sorted(cpu.summary(with_hist=True)["hist"].items()))
     finally:
         dist.destroy_process_group()
 
