@@ -13,8 +13,11 @@ HBM.  value = read k-mers / wall time.  The line also carries: `validate` (assem
 (BASELINE configs[1], 1 M x 150 bp: steady state of several batches into one table and the empty-table figure that
 was round 1's headline), `lookup` and `union` (driver-timed, with their own roofline fractions), `cpu_baseline`.
 
---workload cfg1 and every N > 1 run BASELINE configs[1] per GPU (weak scaling; N > 1 routes records to the owning
-rank with one RCCL all-to-all, kreeq_amd/dist.py).  One JSON line on rank 0.
+N > 1 runs the SAME read set sharded (BASELINE configs[3], strong scaling): every rank generates 1/N of each batch,
+routes the k-mer records to the rank that owns their hash-bucket range with an RCCL all-to-all (kreeq_amd/dist.py),
+and counts what it receives into its 1/N of the table; the assembly is validated by every rank against its own
+buckets and the QV counters are all-reduced.  --workload cfg1 runs BASELINE configs[1] per GPU instead (clear + one
+1 M-read batch per step; weak scaling for N > 1).  One JSON line on rank 0.
 """
 import argparse
 import json
@@ -83,9 +86,7 @@ def main():
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    if world > 1 or args.sharded:
-        args.workload = "cfg1"
-    out = run_human(args, dev) if args.workload == "human" else run_cfg1(args, dev, world, rank, local_rank)
+    out = run_human(args, dev, world, rank) if args.workload == "human" else run_cfg1(args, dev, world, rank, local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
@@ -94,17 +95,19 @@ def main():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def run_human(args, dev):
+def run_human(args, dev, world=1, rank=0):
     import torch
+    import torch.distributed as dist
 
     from kreeq_amd import KreeqDB, synth
 
     k, L = args.k, args.read_len
     G = int(args.genome_mbp * 1e6)
     steps, warmup = args.steps, args.warmup
-    batch_reads = max(1, int(G * COVERAGE / L) // steps)
+    batch_reads = max(world, int(G * COVERAGE / L) // steps) // world * world      # reads per step, all ranks together
     n_reads = batch_reads * steps
     kmers_per_step = batch_reads * (L - k + 1)
+    sharded = world > 1 or args.sharded
 
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
@@ -113,29 +116,47 @@ def run_human(args, dev):
     assembly = synth.ascii_dev(asm_codes)
     del asm_codes
     gen = torch.Generator(device=dev)
-    gen.manual_seed(2)
-    batches = [synth.reads_dev(genome, batch_reads, L, gen, err=ERR) for _ in range(steps)]
+    gen.manual_seed(2 + 1000 * rank)                  # every rank draws its own 1/world of each batch from the same genome
+    batches = [synth.reads_dev(genome, batch_reads // world, L, gen, err=ERR) for _ in range(steps)]
     del genome
     torch.cuda.synchronize(dev)
     torch.cuda.empty_cache()
 
-    # distinct k-mers: the genome's + ~k novel ones per read error (jellyfish -s style bound, 10 % margin)
+    # distinct k-mers: the genome's + ~k novel ones per read error (jellyfish -s style bound, 10 % margin); a rank owns
+    # 1/world of the hash buckets, hence of the k-mers (5 % more room for the spread between ranks)
     hint = int(1.1 * (G + n_reads * L * ERR * k))
-    db = KreeqDB(k, 128, device=dev.index, capacity_hint=hint)
+    counter = None
+    if sharded:
+        from kreeq_amd.dist import GpuEngine, ShardedCounter
+
+        engine = GpuEngine(k, 128, dev.index, capacity_hint=hint if world == 1 else int(1.05 * hint / world))
+        db = engine.db
+        counter = ShardedCounter(engine, k, 128, sharded_path=True)
+        counter.force_exchange = dist.is_initialized()               # world 1 under torchrun: rehearse the RCCL exchange too
+    else:
+        db = KreeqDB(k, 128, device=dev.index, capacity_hint=hint)
+        db.set_stream(stream.cuda_stream)
     db.set_option("trust_capacity", 1)
     db.set_option("count_path", args.path)
     db.set_option("pending_bytes", args.pending_bytes)
-    db.set_stream(stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
     def count(i):
         t = batches[i % steps]
-        db.count_batch_dev(t.data_ptr(), t.numel())
+        if counter is not None:
+            counter.count_batch(t)
+        else:
+            db.count_batch_dev(t.data_ptr(), t.numel())
 
     for i in range(warmup):              # sizes the scratch and the pending-set arena, warms the code objects
         count(i)
     db.sync()
     db.clear()
-    torch.cuda.synchronize(dev)
+    barrier()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -144,28 +165,38 @@ def run_human(args, dev):
         count(i)
     db.sync()                            # applies what is still pending: the table is complete when the clock stops
     ev1.record()
-    torch.cuda.synchronize(dev)
+    barrier()
     dt = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([dt, dev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, dev_ms = float(tt[0]), float(tt[1])
 
-    summ = db.summary()
+    summ = counter.summary() if counter is not None else db.summary()
     assert summ["total"] == kmers_per_step * steps, (summ, kmers_per_step, steps)
     info = db.info()
-    assert info["slots_used"] == summ["distinct"], (info, summ)
+    if world == 1:
+        assert info["slots_used"] == summ["distinct"], (info, summ)
 
-    # validate: the assembly's k-mers against the table (DBG::validateSequences)
-    ctr = torch.zeros(3, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize(dev)
+    # validate: the assembly's k-mers against the table (DBG::validateSequences); N > 1: own buckets + all-reduce
+    barrier()
     tv = time.perf_counter()
-    db.lookup_sequence_dev(assembly.data_ptr(), assembly.numel(), ctr.data_ptr())
-    torch.cuda.synchronize(dev)
+    if counter is not None:
+        c = counter.validate(assembly).tolist()
+    else:
+        ctr = torch.zeros(3, dtype=torch.int64, device=dev)
+        db.lookup_sequence_dev(assembly.data_ptr(), assembly.numel(), ctr.data_ptr())
+        torch.cuda.synchronize(dev)
+        c = ctr.cpu().tolist()
     t_val = time.perf_counter() - tv
-    c = ctr.cpu().tolist()
     assert c[1] == G - k + 1, c
+    if rank != 0:
+        return None
 
     value = kmers_per_step * steps / dt
     ms_kernel = dev_ms / steps
-    achieved = kmers_per_step * BYTES_PER_KMER / (ms_kernel * 1e-3) / 1e9
+    achieved = kmers_per_step / world * BYTES_PER_KMER / (ms_kernel * 1e-3) / 1e9        # per GPU
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
@@ -174,13 +205,14 @@ def run_human(args, dev):
             traffic = tj.get("hbm_bytes_per_launch")
     out = {
         "metric": f"distinct+total k-mers/sec at k={k} (count path)", "value": value, "unit": "k-mers/s",
-        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"configs[2] shape at {G / 3e9:.3f} scale: {G // 1_000_000} Mbp iid genome, {COVERAGE}x {L} bp reads "
-                               f"({n_reads} reads, {ERR * 100:g} % substitutions, generated on the device), k={k}, count in {steps} batches + validate, 1 GPU",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"configs[{3 if world > 1 else 2}] shape at {G / 3e9:.3f} scale: {G // 1_000_000} Mbp iid genome, {COVERAGE}x {L} bp reads "
+                               f"({n_reads} reads, {ERR * 100:g} % substitutions, generated on the device), k={k}, count in {steps} batches + validate, "
+                               + (f"{world} GPUs, hash-bucket sharded with RCCL all-to-all" if world > 1 else "1 GPU"),
                    "genome_bp": G, "reads": n_reads, "reads_per_step": batch_reads, "error_rate": ERR, "table_capacity_kmers": hint,
                    "table_bytes": info["table_bytes"], "table_passes": info["table_passes"], "pending_bytes": args.pending_bytes,
-                   "count_path": args.path, "sharding": "none"},
+                   "count_path": args.path, "sharding": f"bucket x{world}" if sharded else "none"},
         "total_kmers_per_step": kmers_per_step, "distinct_kmers": summ["distinct"], "distinct_kmers_per_s": summ["distinct"] / dt,
         "summary": summ,
         "validate": {"assembly_kmers": c[1], "substitutions": n_sub, "missing": c[0], "edge_missing": c[2], "ms": t_val * 1e3,
@@ -191,13 +223,13 @@ def run_human(args, dev):
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "bytes_per_kmer": BYTES_PER_KMER, "kernel_ms": ms_kernel},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         sample = min(batch_reads, 1_000_000)
         out["cpu_baseline"] = cpu_baseline(batches[0][:sample * (L + 1) - 1].cpu().numpy(), k, L)
     del db, batches, assembly
     torch.cuda.synchronize(dev)
     torch.cuda.empty_cache()
-    if not args.no_extras:
+    if not args.no_extras and world == 1 and not sharded:
         out.update(extras_cfg1(dev, stream))
     return out
 

@@ -176,6 +176,18 @@ int  kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_p
                         uint64_t* d_recs, uint64_t cap, uint64_t* part_counts);
 int  kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n);
 
+/* The same staging with 5-BYTE records (k <= 21, the default k): d_recs[i] (u32) + d_aux[i] (u8) = the hash bits below
+ * the 8-bit hash-prefix bucket of record i and its two edge indices -- the record format of the single-GPU count.  The
+ * part of every owner is one contiguous run (part_counts, host), inside it the records are grouped by bucket:
+ * d_bucket_counts[p * 256 + b] (DEVICE, n_parts x 256) = records of bucket b for part p.  The receiver gets, from every
+ * peer, its run and that peer's 256 counts for it (one all-to-all(v) per array + one all-to-all of 256 counts) and calls
+ * kq_insert_sharded_dev with the runs concatenated in peer order and d_bucket_counts = [n_peers x 256] (DEVICE, peer-
+ * major): the records enter the bucket -> region split levels directly.  The receiving table must have >= 2048 regions.
+ * Buffers need room for len - k + 1 records.  kq_emit_sharded_dev synchronises. */
+int  kq_emit_sharded_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts, uint32_t* d_recs, uint8_t* d_aux, uint64_t cap,
+                         uint64_t* d_bucket_counts, uint64_t* part_counts);
+int  kq_insert_sharded_dev(kq_handle* h, const uint32_t* d_recs, const uint8_t* d_aux, uint64_t n, int n_peers, const uint64_t* d_bucket_counts);
+
 /* Hot loop 2 only (DBG::processBuffers :160-206) on explicit records. */
 int  kq_insert_records(kq_handle* h, const uint64_t* keys, const uint8_t* edges, uint64_t n);
 int  kq_insert_records_dev(kq_handle* h, const uint64_t* d_keys, const uint8_t* d_edges, uint64_t n);

@@ -14,7 +14,7 @@ DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw",
 # every symbol include/kreeq_amd.h declares
 SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_get_profile", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_flush", "kq_get_info", "kq_last_error",
            "kq_abi_version", "kq_device_available", "kq_device_memory", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
-           "kq_emit_partitioned_dev", "kq_emit_packed_dev", "kq_insert_packed_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
+           "kq_emit_partitioned_dev", "kq_emit_packed_dev", "kq_insert_packed_dev", "kq_emit_sharded_dev", "kq_insert_sharded_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
            "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_lookup_keys", "kq_branch_scan", "kq_merge", "kq_import", "kq_export"]
 
 
@@ -96,6 +96,8 @@ def load():
     L.kq_emit_partitioned_dev.argtypes = [vp, vp, u64, ci, vp, vp, u64, vp]
     L.kq_emit_packed_dev.argtypes = [vp, vp, u64, ci, vp, u64, vp]
     L.kq_insert_packed_dev.argtypes = [vp, vp, u64]
+    L.kq_emit_sharded_dev.argtypes = [vp, vp, u64, ci, vp, vp, u64, vp, vp]
+    L.kq_insert_sharded_dev.argtypes = [vp, vp, vp, u64, ci, vp]
     L.kq_insert_records.argtypes = [vp, vp, vp, u64]
     L.kq_insert_records_dev.argtypes = [vp, vp, vp, u64]
     L.kq_summary.argtypes = [vp, C.POINTER(Stats)]
@@ -215,6 +217,15 @@ class KreeqDB:
 
     def insert_packed_dev(self, recs_ptr, n):
         _check(load().kq_insert_packed_dev(self._h, C.c_void_p(recs_ptr), n))
+
+    def emit_sharded_dev(self, bases_ptr, n, n_parts, recs_ptr, aux_ptr, cap, bucket_counts_ptr):
+        counts = np.zeros(n_parts, dtype=np.uint64)
+        _check(load().kq_emit_sharded_dev(self._h, C.c_void_p(bases_ptr), n, n_parts, C.c_void_p(recs_ptr), C.c_void_p(aux_ptr), cap,
+                                          C.c_void_p(bucket_counts_ptr), _p(counts)))
+        return counts
+
+    def insert_sharded_dev(self, recs_ptr, aux_ptr, n, n_peers, bucket_counts_ptr):
+        _check(load().kq_insert_sharded_dev(self._h, C.c_void_p(recs_ptr), C.c_void_p(aux_ptr), n, n_peers, C.c_void_p(bucket_counts_ptr)))
 
     def insert_records(self, keys, edges):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

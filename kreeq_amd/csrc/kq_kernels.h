@@ -227,13 +227,13 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
 // ---- one generic level of the record split (LevelCfg) -----------------------------------------
 // work units: segment b is cut into ceil(size_b / P2_UNIT) units; unit_base = exclusive prefix
 // (one workgroup; n_seg <= SEG_MAX: every thread takes a run of consecutive segments, the run totals are scanned)
-__global__ __launch_bounds__(1024) void k_lv_units(const unsigned long long* __restrict__ seg_off, LevelCfg lv,
+__global__ __launch_bounds__(1024) void k_lv_units(const unsigned long long* __restrict__ seg_off, const unsigned long long* __restrict__ seg_hi, LevelCfg lv,
                                                    unsigned long long* __restrict__ unit_base) {
     __shared__ unsigned long long s_part[1024];
     const uint32_t tid = threadIdx.x, per = (lv.n_seg + 1023) / 1024;
     const uint32_t lo = min(tid * per, lv.n_seg), hi = min(lo + per, lv.n_seg);
     unsigned long long sum = 0;
-    for (uint32_t b = lo; b < hi; ++b) sum += (seg_off[b + 1] - seg_off[b] + P2_UNIT - 1) / P2_UNIT;
+    for (uint32_t b = lo; b < hi; ++b) sum += (seg_hi[b] - seg_off[b] + P2_UNIT - 1) / P2_UNIT;
     s_part[tid] = sum;
     __syncthreads();
     if (tid < 64) {                              // wave 0 scans the 1024 partials, 16 per lane
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(1024) void k_lv_units(const unsigned long long* __r
     }
     __syncthreads();
     unsigned long long run = s_part[tid];
-    for (uint32_t b = lo; b < hi; ++b) { unit_base[b] = run; run += (seg_off[b + 1] - seg_off[b] + P2_UNIT - 1) / P2_UNIT; }
+    for (uint32_t b = lo; b < hi; ++b) { unit_base[b] = run; run += (seg_hi[b] - seg_off[b] + P2_UNIT - 1) / P2_UNIT; }
 }
 __device__ __forceinline__ uint32_t seg_of_unit(const unsigned long long* unit_base, uint32_t n_seg, uint64_t u) {
     uint32_t lo = 0, hi = n_seg;                  // largest b with unit_base[b] <= u (skips empty segments)
@@ -258,22 +258,30 @@ __device__ __forceinline__ uint32_t seg_of_unit(const unsigned long long* unit_b
     return lo;
 }
 // pass A: per-unit bin counts -> M2[unit][bin] (u32)
+// bin of a narrow record in an owner split (LevelCfg::own_parts): the k-mer is recovered from its hash bits
+__device__ __forceinline__ uint32_t owner_bin(const LevelCfg& lv, uint32_t bucket, uint32_t main32, uint32_t aux) {
+    return owner_part_of(key_of_hash(narrow_hash(bucket, main32, aux), lv.k), lv.map_count, lv.map_mask, lv.own_parts);
+}
 template <int FMT>
-__global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restrict__ recs, LevelCfg lv,
-                                                        const unsigned long long* __restrict__ seg_off,
+__global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
+                                                        const unsigned long long* __restrict__ seg_off, const unsigned long long* __restrict__ seg_hi,
                                                         const unsigned long long* __restrict__ unit_base, uint32_t* __restrict__ m2) {
     __shared__ uint32_t s_hist[NB_MAX];
     const uint64_t n_units = unit_base[lv.n_seg];
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const uint32_t b = seg_of_unit(unit_base, lv.n_seg, u);
-        const uint64_t lo = seg_off[b] + (u - unit_base[b]) * P2_UNIT;
-        const uint64_t hi = lo + P2_UNIT < seg_off[b + 1] ? lo + P2_UNIT : seg_off[b + 1];
+        const uint32_t b_in = seg_of_unit(unit_base, lv.n_seg, u);
+        const uint32_t b = lv.spb > 1 ? b_in / lv.spb : b_in;          // logical segment of the bin functions
+        const uint64_t lo = seg_off[b_in] + (u - unit_base[b_in]) * P2_UNIT;
+        const uint64_t hi = lo + P2_UNIT < seg_hi[b_in] ? lo + P2_UNIT : seg_hi[b_in];
         for (uint32_t i = threadIdx.x; i < lv.nb; i += MS_THREADS) s_hist[i] = 0;
         __syncthreads();
         // 8 records per lane in flight, loaded unconditionally (index clamped): a load inside a branch per
         // iteration costs a full memory latency per record (s_waitcnt vmcnt(0) right behind it)
         const uint64_t last = hi - 1;                                   // a unit is never empty
-        if (FMT == FMT_NARROW) {
+        if (FMT == FMT_NARROW && lv.own_parts) {                         // owner split: the bin needs the whole hash (u32 + the byte's low bits)
+            const uint32_t* r32 = reinterpret_cast<const uint32_t*>(recs);
+            for (uint64_t i = lo + threadIdx.x; i < hi; i += MS_THREADS) atomicAdd(&s_hist[owner_bin(lv, b, r32[i], recs_aux[i])], 1u);
+        } else if (FMT == FMT_NARROW) {
             // 16-byte loads of four u32 records at absolute quad indices (the array is 16-byte aligned and has
             // slack behind its last record); the quads at the unit's ends are masked per element
             const uint4* v4 = reinterpret_cast<const uint4*>(recs);
@@ -323,9 +331,11 @@ __global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, L
                                                     unsigned long long* __restrict__ group_count) {
     const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
-    if (r >= (uint64_t)lv.n_seg * lv.nb) return;                     // wave-uniform
-    const uint32_t b = (uint32_t)(r / lv.nb), bin = (uint32_t)(r % lv.nb);
-    const uint64_t u0 = unit_base[b], u1 = unit_base[b + 1];
+    const uint32_t n_lseg = lv.n_seg / lv.spb;                       // logical segments (spb input segments each)
+    if (r >= (uint64_t)n_lseg * lv.nb) return;                       // wave-uniform
+    // group r = (logical segment b, bin): segment-major, or bin-major for an owner split
+    const uint32_t b = lv.own_parts ? (uint32_t)(r % n_lseg) : (uint32_t)(r / lv.nb), bin = lv.own_parts ? (uint32_t)(r / n_lseg) : (uint32_t)(r % lv.nb);
+    const uint64_t u0 = unit_base[b * lv.spb], u1 = unit_base[(b + 1) * lv.spb];
     unsigned long long run = 0;
     for (uint64_t base = u0; base < u1; base += 64) {
         const uint64_t u = base + lane;
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, L
 constexpr int LV_THREADS = KQ_LV_THREADS, LV_ITEMS = KQ_LV_ITEMS, LV_TILE = LV_THREADS * LV_ITEMS;       // records come from memory: more waves per LDS footprint
 template <int FMT, int NBC>
 __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
-                                                           const unsigned long long* __restrict__ seg_off,
+                                                           const unsigned long long* __restrict__ seg_off, const unsigned long long* __restrict__ seg_hi,
                                                            const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
                                                            const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out,
                                                            uint8_t* __restrict__ out_aux) {
@@ -357,11 +367,14 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
     __shared__ MsShared<NBC, MS_FMT, LV_TILE> s;
     const uint32_t nb = lv.nb;
     const uint64_t n_units = unit_base[lv.n_seg];
+    const uint32_t n_lseg = lv.n_seg / lv.spb;
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const uint32_t b = seg_of_unit(unit_base, lv.n_seg, u);
-        const uint64_t lo = seg_off[b] + (u - unit_base[b]) * P2_UNIT;
-        const uint64_t hi = lo + P2_UNIT < seg_off[b + 1] ? lo + P2_UNIT : seg_off[b + 1];
-        for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS) s.gbase[i] = (uint32_t)(group_base[(uint64_t)b * nb + i] + m2[u * nb + i]);
+        const uint32_t b_in = seg_of_unit(unit_base, lv.n_seg, u);
+        const uint32_t b = lv.spb > 1 ? b_in / lv.spb : b_in;          // logical segment: bin functions and output groups
+        const uint64_t lo = seg_off[b_in] + (u - unit_base[b_in]) * P2_UNIT;
+        const uint64_t hi = lo + P2_UNIT < seg_hi[b_in] ? lo + P2_UNIT : seg_hi[b_in];
+        for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS)
+            s.gbase[i] = (uint32_t)(group_base[lv.own_parts ? (uint64_t)i * n_lseg + b : (uint64_t)b * nb + i] + m2[u * nb + i]);
 #ifdef KQ_MS_STAMPS
         if (threadIdx.x == 0) { s.stamp_on = 1; s.stamp_last = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                 const uint64_t i = pos + (uint64_t)j * LV_THREADS + threadIdx.x;
                 rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.k) : nxt[j];      // raw keys become hashes at the first level
                 aux[j] = nxt_aux[j];
-                if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : narrow_bin(lv, b, (uint32_t)rec[j]));
+                if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : lv.own_parts ? owner_bin(lv, b, (uint32_t)rec[j], aux[j]) : narrow_bin(lv, b, (uint32_t)rec[j]));
                 else if (CONVERT) {
                     const uint64_t hh = rec_hash<false>(rec[j]);
                     rec[j] = narrow_word(narrow_main(hh), narrow_aux(hh, (uint32_t)(rec[j] >> REC_EDGE_SHIFT) & 63u), i >= hi ? nb : (uint32_t)(hh >> (64 - NARROW_CBITS)));

@@ -65,6 +65,13 @@ struct LevelCfg {
     // narrow levels: segment b = (bucket b >> nr_shift, sub-bucket b & (2^nr_shift - 1)) starts at region
     // bucket * nr_rps + sub * nr_sub; bin = (region - that) / nr_div (nr_inv = ceil(2^32 / nr_div))
     uint32_t nr_shift, nr_rps, nr_sub, nr_div, nr_inv;
+    // multi-GPU exchange of narrow records:
+    //   spb > 1      the input has spb segments per logical segment (one run per peer rank): input segment s belongs to
+    //                logical segment s / spb, whose units and output groups they share (receive side)
+    //   own_parts    > 0: bin = owner part of the record's k-mer (key % map_count scaled to own_parts, src/graph-builder.cpp:95)
+    //                and the output is BIN-major (group = bin * n_seg + segment): one contiguous run per owner, the records
+    //                of a bucket contiguous inside it (send side)
+    uint32_t spb, own_parts, map_count, map_mask;
 };
 __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, uint64_t region) {
     return (uint32_t)(region >> lv.out_shift) - (lv.seg_shift >= 32 ? 0u : (b << (lv.seg_shift - lv.out_shift)));

@@ -523,7 +523,8 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false
     if (cfg->narrow) { cfg->n_coarse = 1u << NARROW_CBITS; if (cfg->g_shift == 0) cfg->g_shift = 1; }
 }
 // carve the scratch buffer for a batch of at most n_max records; n_tiles = 0 when the input is records
-static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins, bool allow_narrow = false) {
+static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tiles, uint32_t p1_bins, bool allow_narrow = false,
+                      uint64_t min_segs = 0 /*segments / output groups an exchange level needs beyond the table's own*/) {
     if (h->test_fail_plan) { h->test_fail_plan = false; return fail(KQ_ERR_NOMEM, "partition scratch allocation failed (injected by KQ_OPT_TEST_FAIL_PLAN)"); }
     if (n_max >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "a partition pass handles fewer than 2^32 records (got %llu): slice the input", (unsigned long long)n_max);
     plan_cfg(h, &p->cfg, allow_narrow);
@@ -536,9 +537,9 @@ static int plan_alloc(kq_handle* h, PartPlan* p, uint64_t n_max, uint64_t n_tile
     p->g1 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)h->n_cu * (p1_bins < 512 ? 18 : 12)));
     p->m1_n = (uint64_t)p1_bins * p->g1 * P1_F;
     const uint64_t nb_max = std::max<uint64_t>(std::max<uint64_t>(1ull << p->cfg.g_shift, p->cfg.n_coarse), p->cfg.narrow ? (p->cfg.n_regions >> NARROW_CBITS) >> p->cfg.sub_bits : 0);
-    const uint64_t seg_max = p->cfg.narrow ? ((uint64_t)1 << NARROW_CBITS) << p->cfg.sub_bits : (uint64_t)NB_MAX;      // segments of the widest level
+    const uint64_t seg_max = std::max<uint64_t>(min_segs, p->cfg.narrow ? ((uint64_t)1 << NARROW_CBITS) << p->cfg.sub_bits : (uint64_t)NB_MAX);      // segments of the widest level
     p->m2_n = (n_max / P2_UNIT + seg_max + 2) * nb_max;         // u32 entries, enough for either level
-    p->groups_n = std::max<uint64_t>(p->R, (uint64_t)p->cfg.n_coarse << p->cfg.g_shift) + 2;
+    p->groups_n = std::max<uint64_t>(std::max<uint64_t>(p->R, (uint64_t)p->cfg.n_coarse << p->cfg.g_shift), min_segs) + 2;
     p->sums_n = std::max(p->m1_n, p->groups_n) / SCAN_CHUNK + 2;
     const uint64_t aux_words = (n_max + 7) / 8 + 1;
     const uint64_t rec_words = p->fmt == FMT_NARROW ? n_max / 2 + 2 : n_max;          // narrow records: u32 + lockstep byte
@@ -615,25 +616,27 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
 // afterwards p->group_base[0..n_seg*nb] are the output offsets
 static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint64_t* in, const uint8_t* in_aux, uint64_t* out, uint8_t* out_aux,
-                      unsigned long long* gb = nullptr /*where the output offsets go (default p->group_base)*/) {
+                      unsigned long long* gb = nullptr /*where the output offsets go (default p->group_base)*/,
+                      const unsigned long long* seg_hi = nullptr /*end of every input segment (default: the next one's start)*/) {
     if (!gb) gb = p->group_base;
+    if (!seg_hi) seg_hi = p->seg_off + 1;
     const int fmt = lv.narrow == 2 ? FMT_TOP8 : lv.narrow ? FMT_NARROW : in_aux != nullptr ? FMT_WIDE : FMT_PACK8;       // input format; lv.top8: packed in, narrow out
-    const uint64_t groups = (uint64_t)lv.n_seg * lv.nb;
-    hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, lv, p->unit_base);
+    const uint64_t groups = (uint64_t)(lv.n_seg / lv.spb) * lv.nb;
+    hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, seg_hi, lv, p->unit_base);
     // one workgroup per work unit (upper bound of the unit count; surplus workgroups exit at once):
     // the hardware dispatcher balances them, a fixed grid looping over units left a 30 % tail
     const unsigned unit_grid = (unsigned)std::min<uint64_t>(p->n_max / P2_UNIT + lv.n_seg + 1, 1u << 30);
-    if (fmt == FMT_TOP8) hipLaunchKernelGGL(k_lv_hist<FMT_TOP8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
-    else if (fmt == FMT_NARROW) hipLaunchKernelGGL(k_lv_hist<FMT_NARROW>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
-    else if (fmt == FMT_WIDE) hipLaunchKernelGGL(k_lv_hist<FMT_WIDE>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
-    else hipLaunchKernelGGL(k_lv_hist<FMT_PACK8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, lv, p->seg_off, p->unit_base, p->m2);
+    if (fmt == FMT_TOP8) hipLaunchKernelGGL(k_lv_hist<FMT_TOP8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, seg_hi, p->unit_base, p->m2);
+    else if (fmt == FMT_NARROW) hipLaunchKernelGGL(k_lv_hist<FMT_NARROW>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, seg_hi, p->unit_base, p->m2);
+    else if (fmt == FMT_WIDE) hipLaunchKernelGGL(k_lv_hist<FMT_WIDE>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, seg_hi, p->unit_base, p->m2);
+    else hipLaunchKernelGGL(k_lv_hist<FMT_PACK8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, seg_hi, p->unit_base, p->m2);
     hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, gb);
     (void)hipMemsetAsync(gb + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
     scan_u64(h, gb, groups + 1, p->sums, p->total + 1);
     mark(h, "k_lv_hist+offsets+scan");
     const bool small = lv.nb < 512;
 #define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
-                                        p->seg_off, p->unit_base, p->m2, gb, out, out_aux)
+                                        p->seg_off, seg_hi, p->unit_base, p->m2, gb, out, out_aux)
     if (lv.top8)              { KQ_LVS(FMT_PACK8_TO_NARROW, 512); }
     else if (fmt == FMT_TOP8) { if (small) KQ_LVS(FMT_TOP8, 512); else KQ_LVS(FMT_TOP8, NB_MAX); }
     else if (fmt == FMT_NARROW) { if (small) KQ_LVS(FMT_NARROW, 512); else KQ_LVS(FMT_NARROW, NB_MAX); }
@@ -645,6 +648,7 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
+    lv.spb = 1; lv.own_parts = 0; lv.map_count = lv.map_mask = 0;
     return lv;
 }
 // FMT_NARROW: 256 top-bit buckets -> their regions (bucket b owns regions [b * nb, (b + 1) * nb))
@@ -658,6 +662,7 @@ static LevelCfg level_narrow(const PartCfg& cfg, uint32_t sub_bits = 0, bool mid
     if (middle) { lv.n_seg = 1u << NARROW_CBITS; lv.nb = 1u << sub_bits; lv.nr_shift = 0; lv.nr_div = subsz; }
     else        { lv.n_seg = (1u << NARROW_CBITS) << sub_bits; lv.nb = subsz; lv.nr_shift = sub_bits; lv.nr_div = 1; }
     lv.nr_inv = lv.nr_div > 1 ? (uint32_t)(((1ull << 32) + lv.nr_div - 1) / lv.nr_div) : 0;
+    lv.spb = 1; lv.own_parts = 0; lv.map_count = lv.map_mask = 0;
     return lv;
 }
 // bucket -> regions for FMT_NARROW records, in one level or (large tables) two; afterwards `*sorted` holds the
@@ -666,6 +671,7 @@ static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
+    lv.spb = 1; lv.own_parts = 0; lv.map_count = lv.map_mask = 0;
     return lv;
 }
 // ---- pending sets ---------------------------------------------------------------------------------
@@ -1073,6 +1079,106 @@ int kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_pa
     HIPC(hipStreamSynchronize(h->stream));
     for (int i = 0; i < n_parts; ++i) part_counts[i] = off[((size_t)i + 1) << sb] - off[(size_t)i << sb];
     return KQ_OK;
+}
+
+// ---- multi-GPU exchange of 5-byte records (k <= 21) -------------------------------------------------
+// Sender: P1 by hash-prefix bucket (the same 5-byte records the single-GPU count makes), then one split level by OWNER
+// inside every bucket, written owner-major: the part of every destination rank is one contiguous run whose records are
+// grouped by bucket.  Receiver: the runs of all peers are (peer, bucket) segments of its bucket -> region levels, so the
+// received records enter the ordinary narrow path without a conversion level, and 5 bytes per record cross xGMI
+// instead of 8.  kq_emit_packed_dev / kq_insert_packed_dev remain for k = 22..28 and small tables.
+__global__ void k_group_counts(const unsigned long long* __restrict__ group_base, uint64_t n_groups, unsigned long long* __restrict__ counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_groups) counts[i] = group_base[i + 1] - group_base[i];
+}
+// (peer q, bucket b) run j = q * 256 + b of the received array -> input segment b * n_peers + q of the receive levels
+__global__ void k_sharded_segments(const unsigned long long* __restrict__ start /*exclusive scan of the counts, peer-major*/,
+                                   const unsigned long long* __restrict__ counts, uint32_t n_peers,
+                                   unsigned long long* __restrict__ seg_lo, unsigned long long* __restrict__ seg_hi) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_peers << NARROW_CBITS) return;
+    const uint32_t q = j >> NARROW_CBITS, b = j & ((1u << NARROW_CBITS) - 1u);
+    seg_lo[b * n_peers + q] = start[j];
+    seg_hi[b * n_peers + q] = start[j] + counts[j];
+}
+
+int kq_emit_sharded_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts, uint32_t* d_recs, uint8_t* d_aux, uint64_t cap,
+                        uint64_t* d_bucket_counts, uint64_t* part_counts) {
+    if (!h || !part_counts || !d_bucket_counts || n_parts < 1 || n_parts > h->map_count || n_parts > 256 || (!d_bases && len))
+        return fail(KQ_ERR_INVALID, "bad argument");
+    if (h->k > (int)NARROW_MAX_K) return fail(KQ_ERR_INVALID, "5-byte records need k <= %u (use kq_emit_packed_dev)", NARROW_MAX_K);
+    HIPC(hipSetDevice(h->device));
+    for (int i = 0; i < n_parts; ++i) part_counts[i] = 0;
+    const uint64_t n_groups = (uint64_t)n_parts << NARROW_CBITS;
+    HIPC(hipMemsetAsync(d_bucket_counts, 0, n_groups * 8, h->stream));
+    if (len < (uint64_t)h->k) { HIPC(hipStreamSynchronize(h->stream)); return KQ_OK; }
+    if (len - h->k + 1 >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "an owner split handles fewer than 2^32 k-mer starts per call (got %llu): cut the batch", (unsigned long long)(len - h->k + 1));
+    if (cap < len - h->k + 1 || !d_recs || !d_aux) return fail(KQ_ERR_CAPACITY, "record buffers too small: need room for %llu records", (unsigned long long)(len - h->k + 1));
+    const uint8_t* ab; uint64_t lead;
+    aligned_view(d_bases, &ab, &lead);
+    PartPlan p;
+    int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), 1u << NARROW_CBITS, true, n_groups);
+    if (rc) return rc;
+    PartCfg cfg = p.cfg;                                          // bucket = top 8 hash bits, whatever this rank's table looks like
+    cfg.mode = 0; cfg.narrow = 1; cfg.n_coarse = 1u << NARROW_CBITS; cfg.sub_bits = 0; if (cfg.g_shift == 0) cfg.g_shift = 1;
+    run_p1(h, &p, cfg, ab, lead, len, EmitRange{0, ~0ull}, p.recs1, p.aux1, AUX_IDX6);
+    LevelCfg lv = level_narrow(cfg);
+    lv.n_seg = 1u << NARROW_CBITS; lv.nb = (uint32_t)n_parts; lv.own_parts = (uint32_t)n_parts; lv.k = (uint32_t)h->k;
+    lv.map_count = (uint32_t)h->map_count; lv.map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
+    run_level(h, &p, lv, p.recs1, p.aux1, (uint64_t*)d_recs, d_aux);
+    hipLaunchKernelGGL(k_group_counts, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, h->stream, p.group_base, n_groups, (unsigned long long*)d_bucket_counts);
+    std::vector<unsigned long long> off((size_t)n_groups + 1);
+    HIPC(hipMemcpyAsync(off.data(), p.group_base, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n_parts; ++i) part_counts[i] = off[((size_t)i + 1) << NARROW_CBITS] - off[(size_t)i << NARROW_CBITS];
+    return KQ_OK;
+}
+
+int kq_insert_sharded_dev(kq_handle* h, const uint32_t* d_recs, const uint8_t* d_aux, uint64_t n, int n_peers, const uint64_t* d_bucket_counts) {
+    if (!h || ((!d_recs || !d_aux) && n) || !d_bucket_counts || n_peers < 1 || n_peers > 256) return fail(KQ_ERR_INVALID, "bad argument");
+    if (h->k > (int)NARROW_MAX_K) return fail(KQ_ERR_INVALID, "5-byte records need k <= %u (use kq_insert_packed_dev)", NARROW_MAX_K);
+    HIPC(hipSetDevice(h->device));
+    if (!n) return KQ_OK;
+    if (n >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "a partition pass handles fewer than 2^32 records (got %llu)", (unsigned long long)n);
+    int rc = reserve(h, n, n);
+    if (rc) return rc;
+    const uint32_t n_in = (uint32_t)n_peers << NARROW_CBITS;      // input segments: one run per (bucket, peer)
+    PartPlan p;
+    rc = plan_alloc(h, &p, n, 0, 1, true, n_in);
+    if (rc) return rc;
+    if (p.fmt != FMT_NARROW) return fail(KQ_ERR_INVALID, "the table is too small for 5-byte records (fewer than 2048 regions): use kq_insert_packed_dev");
+    // segment table of the received array (peer-major runs) in logical order (bucket-major)
+    rc = ensure_buf(&h->scratch, &h->scratch_bytes, (size_t)(3 * (n_in + 2)) * 8);
+    if (rc) return rc;
+    unsigned long long* start = (unsigned long long*)h->scratch;
+    unsigned long long* seg_lo = start + n_in + 2;
+    unsigned long long* seg_hi = seg_lo + n_in + 2;
+    HIPC(hipMemcpyAsync(start, d_bucket_counts, (size_t)n_in * 8, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, start, (uint64_t)n_in, start + n_in);
+    hipLaunchKernelGGL(k_sharded_segments, dim3((n_in + 255) / 256), dim3(256), 0, h->stream, start, (const unsigned long long*)d_bucket_counts, (uint32_t)n_peers, seg_lo, seg_hi);
+    P3Set set; bool in_arena = false;
+    rc = arena_take(h, p.n_max, p.fmt, p.R, &set, &in_arena); if (rc) return rc;
+    const uint32_t sb = p.cfg.sub_bits;
+    uint64_t* fin = in_arena ? const_cast<uint64_t*>(set.recs) : p.recs2;
+    uint8_t* fin_aux = in_arena ? const_cast<uint8_t*>(set.aux) : p.aux2;
+    unsigned long long* fin_base = in_arena ? const_cast<unsigned long long*>(set.base) : p.group_base;
+    unsigned long long* own_seg_off = p.seg_off;
+    LevelCfg first = level_narrow(p.cfg, sb, sb != 0);
+    first.n_seg = n_in; first.spb = (uint32_t)n_peers;
+    p.seg_off = seg_lo;                                           // the first level reads the received runs
+    if (sb == 0) {
+        run_level(h, &p, first, (const uint64_t*)d_recs, d_aux, fin, fin_aux, fin_base, seg_hi);
+        p.seg_off = own_seg_off;
+    } else {
+        run_level(h, &p, first, (const uint64_t*)d_recs, d_aux, p.recs1, p.aux1, nullptr, seg_hi);
+        p.seg_off = own_seg_off;
+        HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)(((1u << NARROW_CBITS) << sb) + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
+        if (!in_arena) { fin = p.recs2; fin_aux = p.aux2; }
+        run_level(h, &p, level_narrow(p.cfg, sb, false), p.recs1, p.aux1, fin, fin_aux, fin_base);
+    }
+    if (!in_arena) set = P3Set{fin, fin_aux, fin_base, p.n_max};
+    HIPC(hipGetLastError());
+    return pend_or_apply(h, set, FMT_NARROW, AUX_IDX6, in_arena);
 }
 
 int kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n) {

@@ -46,11 +46,24 @@ class GpuEngine:
         self.stream = cur if cur.cuda_stream != 0 else torch.cuda.Stream(self.device)
         self.db.set_stream(self.stream.cuda_stream)
         self._send = {}
+        # 5-byte records (u32 + u8, grouped by owner and hash-prefix bucket) when k <= 21 and the table has the 256-bucket
+        # geometry (>= 2048 regions of 2048 slots); else 8-byte packed records (k <= 28) or key + edge byte
+        self.sharded5 = k <= 21 and self.db.info()["slots_total"] // 2048 >= 2048
 
     def emit_partitioned(self, bases: torch.Tensor, n_parts: int, slot: int = 0):
         """-> ([payload tensors grouped by owner part], per-part record counts).  `slot` selects one of
         two send buffers, so a chunk can be scanned while the previous one is still being exchanged."""
         n = bases.numel()
+        if self.sharded5:
+            buf = self._send.get(("s5", slot))
+            if buf is None or buf[0].numel() < n or buf[2].shape[0] != n_parts:
+                buf = (torch.empty(n, dtype=torch.int32, device=self.device), torch.empty(n, dtype=torch.uint8, device=self.device),
+                       torch.empty((n_parts, 256), dtype=torch.int64, device=self.device))
+                self._send[("s5", slot)] = buf
+            recs, aux, meta = buf
+            counts = self.db.emit_sharded_dev(bases.data_ptr(), n, n_parts, recs.data_ptr(), aux.data_ptr(), recs.numel(), meta.data_ptr())
+            tot = int(counts.sum())
+            return [recs[:tot], aux[:tot]], counts.astype(np.int64), meta
         buf = self._send.get(slot)
         if buf is None or buf[0].numel() < n:
             buf = (torch.empty(n, dtype=torch.int64, device=self.device),
@@ -69,8 +82,10 @@ class GpuEngine:
         """fused K1+K2 (no record materialisation): the single-GPU path"""
         self.db.count_batch_dev(bases.data_ptr(), bases.numel())
 
-    def insert(self, payload):
-        if len(payload) == 1:
+    def insert(self, payload, meta=None):
+        if meta is not None:        # 5-byte records + [n_peers, 256] bucket counts
+            self.db.insert_sharded_dev(payload[0].data_ptr(), payload[1].data_ptr(), payload[0].numel(), meta.shape[0], meta.data_ptr())
+        elif len(payload) == 1:
             self.db.insert_packed_dev(payload[0].data_ptr(), payload[0].numel())
         else:
             self.db.insert_records_dev(payload[0].data_ptr(), payload[1].data_ptr(), payload[0].numel())
@@ -114,6 +129,11 @@ class ShardedCounter:
         if self.world > map_count:
             raise ValueError("more ranks than maps")
         self.map_lo, self.map_hi = owner_range(self.rank, self.world, map_count)
+        # every rank must emit the record format every rank can insert: 5-byte records only if all tables allow them
+        if self.world > 1 and hasattr(engine, "sharded5"):
+            flag = torch.tensor([1 if engine.sharded5 else 0], dtype=torch.int64, device=engine.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            engine.sharded5 = bool(flag.item())
 
     def _stream_ctx(self):
         import contextlib
@@ -152,7 +172,13 @@ class ShardedCounter:
             self._recv[key] = buf
         return buf[:n]
 
-    def _exchange_start(self, payload, send_counts, slot=0):
+    @staticmethod
+    def _emit(engine, bases, world, slot=0):
+        """-> (payload tensors, per-part counts, meta): meta = per-(part, bucket) counts of the 5-byte format, else None"""
+        res = engine.emit_partitioned(bases, world, slot=slot)
+        return res if len(res) == 3 else (res[0], res[1], None)
+
+    def _exchange_start(self, payload, send_counts, slot=0, meta=None):
         """counts first (tiny; its result is needed on the host because all_to_all_single takes host split sizes), then
         one asynchronous all-to-all(v) per payload array into persistent receive buffers"""
         dev = payload[0].device
@@ -167,37 +193,55 @@ class ShardedCounter:
             works.append(dist.all_to_all_single(r, t, output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(),
                                                 group=self.group, async_op=True))
             received.append(r)
-        return received, works, n_recv
+        rmeta = None
+        if meta is not None:                                             # row p of the result = peer p's 256 bucket counts for me
+            rmeta = self._recv_buffer(slot, "meta", meta.numel(), meta).view_as(meta)
+            works.append(dist.all_to_all_single(rmeta, meta, group=self.group, async_op=True))
+        return received, works, n_recv, rmeta
 
     def _count_batch(self, bases: torch.Tensor):
         if self.world == 1 and hasattr(self.engine, "count") and not self.sharded_path:
             self.engine.count(bases)
             return None
         if self.world == 1 and not self.force_exchange:
-            payload, send_counts = self.engine.emit_partitioned(bases, self.world)
-            self.engine.insert(payload)
+            payload, send_counts, meta = self._emit(self.engine, bases, self.world)
+            if meta is not None:
+                self.engine.insert(payload, meta)
+            else:
+                self.engine.insert(payload)
             return int(send_counts.sum())
         # pipeline over chunks: the all-to-all of chunk i runs while chunk i-1 is inserted and chunk
-        # i+1 is scanned (xGMI is point-to-point: the exchange costs about as much as the compute)
+        # i+1 is scanned (xGMI is point-to-point: the exchange costs about as much as the compute).
+        # A chunk stays below 2^27 bases (~1 GB of 8-byte records per all-to-all: larger messages are not safe with
+        # every collective backend); every rank must issue the same number of collectives, so the chunk count is the
+        # maximum over the ranks (one small all-reduce per batch)
         n_total, pending = 0, None
-        chunks = self._cut_points(bases, self.n_chunks)          # exactly n_chunks (possibly empty) chunks on every rank
+        n_chunks = max(self.n_chunks, -(-bases.numel() // self.MAX_CHUNK_BASES))
+        if self.world > 1:
+            nc = torch.tensor([n_chunks], dtype=torch.int64, device=bases.device)
+            dist.all_reduce(nc, op=dist.ReduceOp.MAX, group=self.group)
+            n_chunks = int(nc.item())
+        chunks = self._cut_points(bases, n_chunks)               # exactly n_chunks (possibly empty) chunks on every rank
         for i, (lo, hi) in enumerate(chunks):
             # send buffer i % 2: the exchange of chunk i-2 was waited for before chunk i-1 was started
-            payload, send_counts = self.engine.emit_partitioned(bases[lo:hi], self.world, slot=i % 2)
-            started = self._exchange_start(payload, send_counts, slot=i % 2)
+            payload, send_counts, meta = self._emit(self.engine, bases[lo:hi], self.world, slot=i % 2)
+            started = self._exchange_start(payload, send_counts, slot=i % 2, meta=meta)
             if pending is not None:
-                received, works, _ = pending
-                for w in works:
-                    w.wait()
-                self.engine.insert(received)
+                self._insert_received(pending)
             pending = started
             n_total += started[2]
         if pending is not None:
-            received, works, _ = pending
-            for w in works:
-                w.wait()
-            self.engine.insert(received)
+            self._insert_received(pending)
         return n_total
+
+    def _insert_received(self, pending):
+        received, works, _, rmeta = pending
+        for w in works:
+            w.wait()
+        if rmeta is not None:
+            self.engine.insert(received, rmeta)
+        else:
+            self.engine.insert(received)
 
     def validate(self, bases: torch.Tensor, cov_cutoff=0):
         """every rank passes the SAME assembly sequence; returns the global (missing, total, edgeMissing)"""
@@ -207,6 +251,7 @@ class ShardedCounter:
                 dist.all_reduce(ctr, op=dist.ReduceOp.SUM, group=self.group)
             return ctr.cpu().numpy().astype(np.uint64)
 
+    MAX_CHUNK_BASES = 1 << 27
     HIST_DENSE = 4096        # coverages below this travel as one dense all-reduce; the few above are gathered as pairs
 
     def histogram(self):

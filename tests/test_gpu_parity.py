@@ -807,3 +807,49 @@ def test_lookup_keys_and_branch_scan(kq, O):
                     if edge and (i if fw else 3 - i) != nxt:
                         f |= 2
         assert flags[c] == f, (c, flags[c], f)
+
+
+@pytest.mark.parametrize("k,hint,n_parts,n_peers", [(21, 5_000_000, 3, 2), (21, 40_000_000, 8, 3), (17, 5_000_000, 2, 1), (21, 5_870_000, 5, 4)])
+def test_sharded5_emit_exchange_insert(kq, O, k, hint, n_parts, n_peers):
+    """multi-GPU exchange with 5-byte records, emulated in one process: n_peers senders split their reads by owner part
+    (kq_emit_sharded_dev), each of n_parts receivers gets its run from every peer plus the per-bucket counts and inserts
+    them (kq_insert_sharded_dev) -- every receiver must end up with exactly the oracle's k-mers of the maps it owns"""
+    import torch
+
+    from kreeq_amd.dist import owner_range
+
+    batches = [H.synth_reads(9000 + 700 * q, 150, 300_000, seed=500 + q, err=0.01, n_rate=0.002)[0] for q in range(n_peers)]
+    cpu = O.OracleDB(k, 128)
+    for b in batches:
+        cpu.count_batch(b, threads=8)
+    want = cpu.export()
+    dev = torch.device("cuda", 0)
+    sender = kq.KreeqDB(k, 128)                   # a sender needs no particular table
+    runs, metas = [], []
+    for b in batches:
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        recs = torch.empty(t.numel(), dtype=torch.int32, device=dev)
+        aux = torch.empty(t.numel(), dtype=torch.uint8, device=dev)
+        meta = torch.empty((n_parts, 256), dtype=torch.int64, device=dev)
+        counts = sender.emit_sharded_dev(t.data_ptr(), t.numel(), n_parts, recs.data_ptr(), aux.data_ptr(), recs.numel(), meta.data_ptr())
+        assert meta.sum(dim=1).cpu().tolist() == counts.tolist()
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        runs.append([(recs[off[p]:off[p + 1]].clone(), aux[off[p]:off[p + 1]].clone()) for p in range(n_parts)])
+        metas.append(meta.clone())
+    total = 0
+    for p in range(n_parts):
+        recv = kq.KreeqDB(k, 128, capacity_hint=hint)
+        recv.set_option("trust_capacity", 1)
+        r = torch.cat([runs[q][p][0] for q in range(n_peers)])
+        a = torch.cat([runs[q][p][1] for q in range(n_peers)])
+        m = torch.stack([metas[q][p] for q in range(n_peers)]).contiguous()
+        recv.insert_sharded_dev(r.data_ptr(), a.data_ptr(), r.numel(), n_peers, m.data_ptr())
+        # a second, pending-set round on the filled table: the same records again double every count
+        recv.insert_sharded_dev(r.data_ptr(), a.data_ptr(), r.numel(), n_peers, m.data_ptr())
+        got = recv.export()
+        lo, hi = owner_range(p, n_parts, 128)
+        mine = want[(want["key"] % np.uint64(128) >= lo) & (want["key"] % np.uint64(128) < hi)]
+        assert len(got) == len(mine) and np.array_equal(got["key"], mine["key"])
+        assert np.array_equal(got["cov"], 2 * mine["cov"]) and np.array_equal(got["fw"], 2 * mine["fw"]) and np.array_equal(got["bw"], 2 * mine["bw"])
+        total += len(got)
+    assert total == len(want)
