@@ -279,8 +279,24 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
         // iteration costs a full memory latency per record (s_waitcnt vmcnt(0) right behind it)
         const uint64_t last = hi - 1;                                   // a unit is never empty
         if (FMT == FMT_NARROW && lv.own_parts) {                         // owner split: the bin needs the whole hash (u32 + the byte's low bits)
+            // few bins: 2^rs counters per bin (by lane), folded below -- one counter per owner would serialise the atomics
             const uint32_t* r32 = reinterpret_cast<const uint32_t*>(recs);
-            for (uint64_t i = lo + threadIdx.x; i < hi; i += MS_THREADS) atomicAdd(&s_hist[owner_bin(lv, b, r32[i], recs_aux[i])], 1u);
+            const uint32_t rs = lv.rep_shift, sub = threadIdx.x & ((1u << rs) - 1u);
+            for (uint32_t i = lv.nb + threadIdx.x; i < (lv.nb << rs); i += MS_THREADS) s_hist[i] = 0;
+            __syncthreads();
+            for (uint64_t base = lo; base < hi; base += 4ull * MS_THREADS) {
+                uint32_t r[4], a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const uint64_t i = min(base + (uint64_t)j * MS_THREADS + threadIdx.x, last); r[j] = r32[i]; a[j] = recs_aux[i]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi) atomicAdd(&s_hist[(owner_bin(lv, b, r[j], a[j]) << rs) | sub], 1u);
+            }
+            __syncthreads();
+            uint32_t folded = 0;
+            if (threadIdx.x < lv.nb) for (uint32_t c = 0; c < (1u << rs); ++c) folded += s_hist[(threadIdx.x << rs) | c];
+            __syncthreads();
+            if (threadIdx.x < lv.nb) s_hist[threadIdx.x] = folded;
         } else if (FMT == FMT_NARROW) {
             // 16-byte loads of four u32 records at absolute quad indices (the array is 16-byte aligned and has
             // slack behind its last record); the quads at the unit's ends are masked per element
@@ -420,7 +436,7 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
             block_multisplit<MS_FMT, LV_THREADS, LV_ITEMS>(s, rec, aux, bin, nb, out, out_aux, [&] {
 #pragma unroll
                 for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); if (HAS_AUX) landed(nxt_aux[j]); }
-            });
+            }, NBC <= 512 ? lv.rep_shift : 0u);
         }
     }
 }

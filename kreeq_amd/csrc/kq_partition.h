@@ -72,6 +72,7 @@ struct LevelCfg {
     //                and the output is BIN-major (group = bin * n_seg + segment): one contiguous run per owner, the records
     //                of a bucket contiguous inside it (send side)
     uint32_t spb, own_parts, map_count, map_mask;
+    uint32_t rep_shift;     // rank replication of the multisplit (block_multisplit's rs), set by the host from nb
 };
 __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, uint64_t region) {
     return (uint32_t)(region >> lv.out_shift) - (lv.seg_shift >= 32 ? 0u : (b << (lv.seg_shift - lv.out_shift)));
@@ -207,13 +208,17 @@ __device__ __forceinline__ void ms_scan(S& s, uint32_t nb) {
 __device__ __forceinline__ void landed(uint32_t& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void landed(uint64_t& v) { asm volatile("" : "+v"(v)); }
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `rs` (rank replication): every bin gets 2^rs rank counters, chosen by lane, and the staged order is (bin, counter):
+// the records of a bin stay contiguous, but a split with few bins no longer serialises its rank atomics on a few LDS
+// addresses (an 8-way owner split puts 512 records of a round on each counter otherwise).  (nb + 1) << rs <= NBC.
 template <int FMT, int THREADS = MS_THREADS, int ITEMS = MS_ITEMS, class S, class F = NoHook>
 __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITEMS], const uint32_t (&aux)[ITEMS],
                                                  const uint32_t (&bin)[ITEMS], uint32_t nb,
-                                                 uint64_t* __restrict__ out, uint8_t* __restrict__ out_aux, F pre_store = F()) {
+                                                 uint64_t* __restrict__ out, uint8_t* __restrict__ out_aux, F pre_store = F(), uint32_t rs = 0) {
     const int tid = threadIdx.x;
+    const uint32_t sub = (uint32_t)tid & ((1u << rs) - 1u), n_ctr = (nb + 1) << rs;
     KQ_MS_STAMP(s, 0);                            // caller: loads landed, bins computed
-    for (uint32_t b = tid; b <= nb; b += THREADS) s.hist[b] = 0;
+    for (uint32_t b = tid; b < n_ctr; b += THREADS) s.hist[b] = 0;
     __syncthreads();
     KQ_MS_STAMP(s, 1);                            // zero hist + barrier
     static_assert(THREADS * ITEMS <= S::tile, "round size");
@@ -221,17 +226,17 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     // bin[] are not read, which saves the caller 2 x ITEMS registers
     uint32_t rank[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) rank[i] = atomicAdd(&s.hist[FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i]], 1u);
+    for (int i = 0; i < ITEMS; ++i) rank[i] = atomicAdd(&s.hist[((FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i]) << rs) | sub], 1u);
     __syncthreads();
     KQ_MS_STAMP(s, 2);                            // rank atomics + barrier
-    ms_scan<THREADS>(s, nb + 1);
+    ms_scan<THREADS>(s, n_ctr);
     KQ_MS_STAMP(s, 3);                            // scan (2 barriers)
     // from here to the end of the round gbase[b] is relative to the staged order: the output index of the
     // staged record j of bin b is gbase[b] + j (one LDS read per record in the copy-out instead of two)
-    for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] -= s.loff[b];
+    for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] -= s.loff[b << rs];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t p = s.loff[FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i]] + rank[i];
+        const uint32_t p = s.loff[((FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i]) << rs) | sub] + rank[i];
         if (FMT == FMT_NARROW) {
             s.stage[p] = rec[i];                                        // one 8-byte write, no sub-dword traffic
         } else {
@@ -242,7 +247,7 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     }
     __syncthreads();
     KQ_MS_STAMP(s, 4);                            // stage writes + barrier
-    const uint32_t total = s.loff[nb];           // records in front of the discard bin
+    const uint32_t total = s.loff[nb << rs];     // records in front of the discard bin
     // fully unrolled so that the LDS reads of all ITEMS positions are in flight together (a rolled
     // loop is a chain of three dependent LDS round trips per record)
     uint32_t cb[ITEMS];
@@ -275,8 +280,9 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     }
     __syncthreads();
     KQ_MS_STAMP(s, 7);                            // global stores issued + barrier
-    // advance the cursors; the same thread zeroes hist[b] at the start of the next round
-    for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] += s.loff[b] + s.hist[b];       // back to absolute, advanced
+    // advance the cursors: gbase[b] + loff[first counter of bin b] is the absolute cursor, the bin's count of this round is
+    // the distance to the first counter of the next bin
+    for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] += s.loff[(b + 1) << rs];     // (loff is next written behind the next round's barriers)
 }
 
 // owner part of a key in the multi-GPU exchange: floor((key % map_count) * n_parts / map_count)

@@ -620,22 +620,26 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
                       const unsigned long long* seg_hi = nullptr /*end of every input segment (default: the next one's start)*/) {
     if (!gb) gb = p->group_base;
     if (!seg_hi) seg_hi = p->seg_off + 1;
+    LevelCfg lvr = lv;                                            // rank replication: as many counters per bin as fit 512 (at most 64, one per lane)
+    lvr.rep_shift = 0;
+    while (lvr.rep_shift < 6 && (((uint64_t)lv.nb + 1) << (lvr.rep_shift + 1)) <= 512) ++lvr.rep_shift;
+    const LevelCfg& lv_ = lvr;
     const int fmt = lv.narrow == 2 ? FMT_TOP8 : lv.narrow ? FMT_NARROW : in_aux != nullptr ? FMT_WIDE : FMT_PACK8;       // input format; lv.top8: packed in, narrow out
     const uint64_t groups = (uint64_t)(lv.n_seg / lv.spb) * lv.nb;
-    hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, seg_hi, lv, p->unit_base);
+    hipLaunchKernelGGL(k_lv_units, dim3(1), dim3(1024), 0, h->stream, p->seg_off, seg_hi, lv_, p->unit_base);
     // one workgroup per work unit (upper bound of the unit count; surplus workgroups exit at once):
     // the hardware dispatcher balances them, a fixed grid looping over units left a 30 % tail
     const unsigned unit_grid = (unsigned)std::min<uint64_t>(p->n_max / P2_UNIT + lv.n_seg + 1, 1u << 30);
-    if (fmt == FMT_TOP8) hipLaunchKernelGGL(k_lv_hist<FMT_TOP8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, seg_hi, p->unit_base, p->m2);
-    else if (fmt == FMT_NARROW) hipLaunchKernelGGL(k_lv_hist<FMT_NARROW>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, seg_hi, p->unit_base, p->m2);
-    else if (fmt == FMT_WIDE) hipLaunchKernelGGL(k_lv_hist<FMT_WIDE>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, seg_hi, p->unit_base, p->m2);
-    else hipLaunchKernelGGL(k_lv_hist<FMT_PACK8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv, p->seg_off, seg_hi, p->unit_base, p->m2);
-    hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv, p->unit_base, gb);
+    if (fmt == FMT_TOP8) hipLaunchKernelGGL(k_lv_hist<FMT_TOP8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv_, p->seg_off, seg_hi, p->unit_base, p->m2);
+    else if (fmt == FMT_NARROW) hipLaunchKernelGGL(k_lv_hist<FMT_NARROW>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv_, p->seg_off, seg_hi, p->unit_base, p->m2);
+    else if (fmt == FMT_WIDE) hipLaunchKernelGGL(k_lv_hist<FMT_WIDE>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv_, p->seg_off, seg_hi, p->unit_base, p->m2);
+    else hipLaunchKernelGGL(k_lv_hist<FMT_PACK8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv_, p->seg_off, seg_hi, p->unit_base, p->m2);
+    hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv_, p->unit_base, gb);
     (void)hipMemsetAsync(gb + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
     scan_u64(h, gb, groups + 1, p->sums, p->total + 1);
     mark(h, "k_lv_hist+offsets+scan");
     const bool small = lv.nb < 512;
-#define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv, \
+#define KQ_LVS(W, N) hipLaunchKernelGGL((k_lv_scatter<W, N>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, in, in_aux, lv_, \
                                         p->seg_off, seg_hi, p->unit_base, p->m2, gb, out, out_aux)
     if (lv.top8)              { KQ_LVS(FMT_PACK8_TO_NARROW, 512); }
     else if (fmt == FMT_TOP8) { if (small) KQ_LVS(FMT_TOP8, 512); else KQ_LVS(FMT_TOP8, NB_MAX); }
