@@ -138,7 +138,14 @@ def run_human(args, dev, world=1, rank=0):
         db.set_stream(stream.cuda_stream)
     db.set_option("trust_capacity", 1)
     db.set_option("count_path", args.path)
-    db.set_option("pending_bytes", args.pending_bytes)
+    # pending-set arena: the library's automatic arena starts small and doubles when it fills up (a short job never pays
+    # for tens of GB of hipMalloc); a job that knows it is long sizes it once, here to the automatic ceiling: a few times
+    # the table, at most half of the HBM that is free now -- allocated by the first warm-up step, outside the timed region
+    pending = args.pending_bytes
+    if pending == -1:
+        from kreeq_amd.capi import device_memory
+        pending = int(min(device_memory(dev.index)[0] // 2, 4 * db.info()["table_bytes"]))
+    db.set_option("pending_bytes", pending)
 
     def barrier():
         if world > 1:
@@ -211,7 +218,7 @@ def run_human(args, dev, world=1, rank=0):
                                f"({n_reads} reads, {ERR * 100:g} % substitutions, generated on the device), k={k}, count in {steps} batches + validate, "
                                + (f"{world} GPUs, hash-bucket sharded with RCCL all-to-all" if world > 1 else "1 GPU"),
                    "genome_bp": G, "reads": n_reads, "reads_per_step": batch_reads, "error_rate": ERR, "table_capacity_kmers": hint,
-                   "table_bytes": info["table_bytes"], "table_passes": info["table_passes"], "pending_bytes": args.pending_bytes,
+                   "table_bytes": info["table_bytes"], "table_passes": info["table_passes"], "pending_bytes": pending,
                    "count_path": args.path, "sharding": f"bucket x{world}" if sharded else "none"},
         "total_kmers_per_step": kmers_per_step, "distinct_kmers": summ["distinct"], "distinct_kmers_per_s": summ["distinct"] / dt,
         "summary": summ,

@@ -153,6 +153,17 @@ int  kq_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 int  kq_count_batch(kq_handle* h, const char* bases, uint64_t len);
 int  kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len);
 
+/* Pipelined host ingest (what gfalibs' loadKmers reader thread + readBatches queue are to the reference, src/input.cpp:95-96):
+ * kq_count_batch_async enqueues the host-to-device copy of a batch on a copy stream and its count behind it, and returns
+ * at once; copies overlap the counting of earlier batches (a small ring of device staging buffers).  `bases` should come
+ * from kq_host_alloc (pinned memory: the copy is a DMA at PCIe rate); the buffer may be refilled once kq_host_wait(ticket)
+ * has returned.  Calls on one handle must still be serialised (a mutex around kq_count_batch_async is enough: it does
+ * not block on the GPU).  kq_sync() drains everything. */
+void* kq_host_alloc(uint64_t bytes);
+void  kq_host_free(void* p);
+int  kq_count_batch_async(kq_handle* h, const char* bases, uint64_t len, uint64_t* ticket);
+int  kq_host_wait(kq_handle* h, uint64_t ticket);
+
 /* Hot loop 1 only (DBG::hashSequences :75-113): the (key, edge byte) records of a batch in
  * sequence order; edge byte layout = edgeBit (include/kreeq.h:6-18).  *n_out = number of records
  * (also set on KQ_ERR_CAPACITY).  keys/edges may be NULL to just count. */

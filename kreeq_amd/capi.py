@@ -13,7 +13,7 @@ DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw",
 
 # every symbol include/kreeq_amd.h declares
 SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_get_profile", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_flush", "kq_get_info", "kq_last_error",
-           "kq_abi_version", "kq_device_available", "kq_device_memory", "kq_count_batch", "kq_count_batch_dev", "kq_emit_records",
+           "kq_abi_version", "kq_device_available", "kq_device_memory", "kq_count_batch", "kq_count_batch_dev", "kq_host_alloc", "kq_host_free", "kq_count_batch_async", "kq_host_wait", "kq_emit_records",
            "kq_emit_partitioned_dev", "kq_emit_packed_dev", "kq_insert_packed_dev", "kq_emit_sharded_dev", "kq_insert_sharded_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
            "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_lookup_keys", "kq_branch_scan", "kq_merge", "kq_import", "kq_export"]
 
@@ -92,6 +92,12 @@ def load():
     L.kq_device_memory.argtypes = [ci, C.POINTER(u64), C.POINTER(u64)]
     L.kq_count_batch.argtypes = [vp, vp, u64]
     L.kq_count_batch_dev.argtypes = [vp, vp, u64]
+    L.kq_host_alloc.argtypes = [u64]
+    L.kq_host_alloc.restype = vp
+    L.kq_host_free.argtypes = [vp]
+    L.kq_host_free.restype = None
+    L.kq_count_batch_async.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.kq_host_wait.argtypes = [vp, u64]
     L.kq_emit_records.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
     L.kq_emit_partitioned_dev.argtypes = [vp, vp, u64, ci, vp, vp, u64, vp]
     L.kq_emit_packed_dev.argtypes = [vp, vp, u64, ci, vp, u64, vp]
@@ -190,6 +196,16 @@ class KreeqDB:
     def count_batch(self, bases: bytes):
         buf = np.frombuffer(bases, dtype=np.uint8)
         _check(load().kq_count_batch(self._h, _p(buf), len(buf)))
+
+    def count_batch_async(self, host_ptr, n):
+        """pipelined ingest: enqueue copy + count of a host batch (pinned memory from host_alloc); returns the ticket to wait
+        on before the buffer is refilled"""
+        t = C.c_uint64(0)
+        _check(load().kq_count_batch_async(self._h, C.c_void_p(host_ptr), n, C.byref(t)))
+        return t.value
+
+    def host_wait(self, ticket):
+        _check(load().kq_host_wait(self._h, ticket))
 
     def count_batch_dev(self, ptr, n):
         _check(load().kq_count_batch_dev(self._h, C.c_void_p(ptr), n))

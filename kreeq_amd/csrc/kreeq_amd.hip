@@ -79,6 +79,13 @@ struct kq_handle {
     uint64_t pend_records = 0;           // upper bound of the records in the pending sets
     int64_t pend_budget = -1;            // KQ_OPT_PENDING_BYTES: -1 auto, 0 = apply every slice at once
     uint64_t table_passes = 0;           // k_count_regions passes so far
+    // pipelined host ingest (kq_count_batch_async): copies on their own stream into a ring of device staging buffers
+    static constexpr int IN_SLOTS = 3, IN_TICKETS = 4096;
+    hipStream_t copy_stream = nullptr;
+    void* in_buf[IN_SLOTS] = {nullptr, nullptr, nullptr}; size_t in_bytes[IN_SLOTS] = {0, 0, 0};
+    hipEvent_t in_consumed[IN_SLOTS] = {nullptr, nullptr, nullptr};      // the count that read the slot has been enqueued and finished
+    std::vector<hipEvent_t> in_copied;   // ring of "copy of ticket t done" events
+    uint64_t in_next = 0;
     bool test_fail_plan = false;         // KQ_OPT_TEST_FAIL_PLAN: the next partition plan fails with KQ_ERR_NOMEM (failure-path tests)
     void* hot = nullptr; size_t hot_bytes = 0;         // k_count_regions' list of skewed regions
 
@@ -368,6 +375,9 @@ void kq_destroy(kq_handle* h) {
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->stage) (void)hipFree(h->stage);
     if (h->part) (void)hipFree(h->part);
+    for (int i = 0; i < kq_handle::IN_SLOTS; ++i) { if (h->in_buf[i]) (void)hipFree(h->in_buf[i]); if (h->in_consumed[i]) (void)hipEventDestroy(h->in_consumed[i]); }
+    for (auto e : h->in_copied) (void)hipEventDestroy(e);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->arena) (void)hipFree(h->arena);
     if (h->d_sets) (void)hipFree(h->d_sets);
     if (h->hot) (void)hipFree(h->hot);
@@ -634,7 +644,11 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     else if (fmt == FMT_NARROW) hipLaunchKernelGGL(k_lv_hist<FMT_NARROW>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv_, p->seg_off, seg_hi, p->unit_base, p->m2);
     else if (fmt == FMT_WIDE) hipLaunchKernelGGL(k_lv_hist<FMT_WIDE>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv_, p->seg_off, seg_hi, p->unit_base, p->m2);
     else hipLaunchKernelGGL(k_lv_hist<FMT_PACK8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv_, p->seg_off, seg_hi, p->unit_base, p->m2);
-    hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv_, p->unit_base, gb);
+    // few units per segment (many segments): one thread per group; else one wave per group (a segment of thousands of units)
+    if (p->n_max / P2_UNIT + 1 <= 8 * (uint64_t)(lv.n_seg / lv.spb) && !lv.own_parts)
+        hipLaunchKernelGGL(k_lv_offsets_thread, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv_, p->unit_base, gb);
+    else
+        hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv_, p->unit_base, gb);
     (void)hipMemsetAsync(gb + groups, 0, 8, h->stream);   // failure surfaces at the caller's hipGetLastError
     scan_u64(h, gb, groups + 1, p->sums, p->total + 1);
     mark(h, "k_lv_hist+offsets+scan");
@@ -698,20 +712,30 @@ static int arena_take(kq_handle* h, uint64_t n_max, int fmt, uint64_t R, P3Set* 
     *ok = false;
     if (h->pend_budget == 0) return KQ_OK;
     const size_t need = set_bytes(n_max, fmt, R);
+    bool was_full = false;
     if (h->n_pend && (h->n_pend >= P3_MAX_SETS || h->pend_fmt != fmt || h->arena_used + need > h->arena_bytes)) {
+        was_full = h->pend_fmt == fmt && h->n_pend < P3_MAX_SETS;
         int rc = flush_pending(h);
         if (rc) return rc;
     }
-    if (need > h->arena_bytes) {
-        // (re)size the arena: a few sets, a few times the table, at most half of what is free
+    // The arena starts at a few sets and doubles every time it fills up, up to a few times the table and half of what is
+    // free (a fixed KQ_OPT_PENDING_BYTES is taken as it is): a short job never pays for allocating tens of GB (hipMalloc
+    // costs milliseconds per GB), a long one gets there within its first batches
+    size_t want = h->arena_bytes;
+    if (need > want) want = h->pend_budget > 0 ? (size_t)h->pend_budget : std::max<size_t>(4 * need, (size_t)64 << 20);
+    else if (was_full && h->pend_budget < 0) want = 2 * h->arena_bytes;
+    if (want > h->arena_bytes) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return KQ_OK;
-        size_t budget = h->pend_budget > 0 ? (size_t)h->pend_budget
-                                           : std::min<size_t>((free_b + h->arena_bytes) / 2, std::max<size_t>(4 * need, 4 * (size_t)h->n_slots() * sizeof(Slot)));
-        if (budget < need) return KQ_OK;
-        if (h->arena) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
-        if (hipMalloc(&h->arena, budget) != hipSuccess) { (void)hipGetLastError(); h->arena = nullptr; return KQ_OK; }
-        h->arena_bytes = budget; h->arena_used = 0;
+        size_t budget = want;
+        if (h->pend_budget < 0) budget = std::min<size_t>(want, std::min<size_t>((free_b + h->arena_bytes) / 2, std::max<size_t>(4 * need, 4 * (size_t)h->n_slots() * sizeof(Slot))));
+        if (budget <= h->arena_bytes && need <= h->arena_bytes) budget = 0;         // at its ceiling already
+        if (budget && budget < need) return KQ_OK;
+        if (budget) {
+            if (h->arena) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
+            if (hipMalloc(&h->arena, budget) != hipSuccess) { (void)hipGetLastError(); h->arena = nullptr; return KQ_OK; }
+            h->arena_bytes = budget; h->arena_used = 0;
+        }
     }
     uint8_t* base = (uint8_t*)h->arena + h->arena_used;
     const size_t rec = fmt == FMT_NARROW ? 4 : 8;
@@ -971,6 +995,50 @@ int kq_count_batch(kq_handle* h, const char* bases, uint64_t len) {
     // the staging buffer is free again once the stream has drained; records may stay pending (errors of a pending
     // pass surface at the next kq_sync / read of the table)
     HIPC(hipStreamSynchronize(h->stream));
+    return KQ_OK;
+}
+
+void* kq_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void kq_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int kq_count_batch_async(kq_handle* h, const char* bases, uint64_t len, uint64_t* ticket) {
+    if (!h || !ticket || (!bases && len)) return fail(KQ_ERR_INVALID, "null argument");
+    HIPC(hipSetDevice(h->device));
+    if (!h->copy_stream) {
+        HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < kq_handle::IN_SLOTS; ++i) HIPC(hipEventCreateWithFlags(&h->in_consumed[i], hipEventDisableTiming));
+        h->in_copied.resize(kq_handle::IN_TICKETS);
+        for (auto& e : h->in_copied) HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const uint64_t t = h->in_next++;
+    const int s = (int)(t % kq_handle::IN_SLOTS);
+    hipEvent_t copied = h->in_copied[t % kq_handle::IN_TICKETS];
+    *ticket = t;
+    // the slot's previous reader must be done before it is overwritten (copy stream waits; the host does not)
+    if (t >= (uint64_t)kq_handle::IN_SLOTS) HIPC(hipStreamWaitEvent(h->copy_stream, h->in_consumed[s], 0));
+    if (h->in_bytes[s] < len + 64) {
+        // growing a slot: nothing may still read the old buffer
+        if (h->in_buf[s]) { HIPC(hipStreamSynchronize(h->copy_stream)); HIPC(hipStreamSynchronize(h->stream)); HIPC(hipFree(h->in_buf[s])); h->in_buf[s] = nullptr; h->in_bytes[s] = 0; }
+        const size_t want = (size_t)len + len / 4 + 4096;
+        HIPC(hipMalloc(&h->in_buf[s], want));
+        h->in_bytes[s] = want;
+    }
+    if (len) HIPC(hipMemcpyAsync(h->in_buf[s], bases, len, hipMemcpyHostToDevice, h->copy_stream));
+    HIPC(hipEventRecord(copied, h->copy_stream));
+    HIPC(hipStreamWaitEvent(h->stream, copied, 0));
+    int rc = kq_count_batch_dev(h, (const char*)h->in_buf[s], len);
+    HIPC(hipEventRecord(h->in_consumed[s], h->stream));
+    return rc;
+}
+int kq_host_wait(kq_handle* h, uint64_t ticket) {
+    if (!h) return fail(KQ_ERR_INVALID, "null handle");
+    if (ticket >= h->in_next) return fail(KQ_ERR_INVALID, "unknown ticket %llu", (unsigned long long)ticket);
+    if (h->in_next - ticket >= (uint64_t)kq_handle::IN_TICKETS) return KQ_OK;      // long recycled: that copy finished many batches ago
+    HIPC(hipEventSynchronize(h->in_copied[ticket % kq_handle::IN_TICKETS]));
     return KQ_OK;
 }
 

@@ -307,4 +307,114 @@ void read_batches_parallel(const std::string& path, size_t batch_bytes, unsigned
     close(fd);
 }
 
+namespace {
+
+// one parser thread's current buffer of a BatchSink
+struct Appender {
+    const BatchSink& sink;
+    unsigned t;
+    char* buf = nullptr;
+    size_t cap = 0, len = 0;
+    Appender(const BatchSink& s, unsigned thread) : sink(s), t(thread) {}
+    // room for a sequence of n bases (and its separator) in the current buffer, else submit it and take a fresh one
+    void reserve(size_t n) {
+        if (buf && len + n + 1 <= cap) return;
+        flush();
+        buf = sink.acquire(t, &cap);
+        len = 0;
+        if (n + 1 > cap) throw std::runtime_error("sequence of " + std::to_string(n) + " bases does not fit a " + std::to_string(cap) + "-byte read batch");
+    }
+    void begin() { if (len) buf[len++] = '\n'; }
+    void piece(const char* a, const char* b) { memcpy(buf + len, a, (size_t)(b - a)); len += (size_t)(b - a); }
+    void flush() { if (buf && len) sink.submit(t, buf, len); buf = nullptr; len = 0; }
+};
+inline const char* trim_eol(const char* a, const char* b) { while (b > a && (b[-1] == '\n' || b[-1] == '\r')) --b; return b; }
+
+}  // namespace
+
+void read_batches_sink(const std::string& path, unsigned threads, const BatchSink& sink) {
+    if (threads < 1) threads = 1;
+    struct stat st;
+    const bool gz = path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    int fd = -1;
+    const char* data = nullptr;
+    size_t size = 0;
+    if (!gz && stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd >= 0) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { data = (const char*)m; size = (size_t)st.st_size; madvise(m, size, MADV_SEQUENTIAL); }
+        }
+    }
+    if (!data || (data[0] != '@' && data[0] != '>')) {
+        // compressed / piped / unknown: the sequential reader feeds buffer after buffer on this thread
+        if (data) munmap((void*)data, size);
+        if (fd >= 0) close(fd);
+        Appender ap(sink, 0);
+        read_fastx(path, [&](SeqRecord&& r) { ap.reserve(r.seq.size()); ap.begin(); ap.piece(r.seq.data(), r.seq.data() + r.seq.size()); });
+        ap.flush();
+        return;
+    }
+    const bool fastq = data[0] == '@';
+    const char* begin = data;
+    const char* end = data + size;
+    const size_t chunk = std::max<size_t>((size_t)4 << 20, std::min<size_t>((size_t)32 << 20, size / (threads * 4) + 1));
+    const size_t n_chunks = (size + chunk - 1) / chunk;
+    std::mutex next_m;
+    size_t next_chunk = 0;
+    std::string first_error;
+    bool failed = false;
+    auto worker = [&](unsigned t) {
+        Appender ap(sink, t);
+        try {
+            for (;;) {
+                size_t c;
+                { std::lock_guard<std::mutex> l(next_m); if (failed) break; c = next_chunk++; }
+                if (c >= n_chunks) break;
+                const char* lo = begin + c * chunk;
+                const char* hi = std::min(end, lo + chunk);
+                const char* p = fastq ? fastq_sync(lo, begin, end) : fasta_sync(lo, begin, end);
+                if (c == 0 && p != begin) throw std::runtime_error("malformed " + std::string(fastq ? "FASTQ" : "FASTA") + " record at the start of " + path);
+                while (p < hi) {
+                    if (fastq) {
+                        const char* seq = next_line(p, end);
+                        const char* plus = next_line(seq, end);
+                        const char* qual = next_line(plus, end);
+                        if (*p != '@' || (plus < end && *plus != '+'))
+                            throw std::runtime_error("malformed FASTQ record (four-line records expected) at byte " + std::to_string((size_t)(p - begin)) + " of " + path);
+                        const char* e = trim_eol(seq, plus);
+                        ap.reserve((size_t)(e - seq));
+                        ap.begin();
+                        ap.piece(seq, e);
+                        p = next_line(qual, end);
+                    } else {
+                        const char* seq = next_line(p, end);
+                        const char* nxt = seq;
+                        size_t total = 0;
+                        while (nxt < end && *nxt != '>') { const char* e = next_line(nxt, end); total += (size_t)(trim_eol(nxt, e) - nxt); nxt = e; }
+                        ap.reserve(total);
+                        ap.begin();
+                        for (const char* s = seq; s < nxt;) { const char* e = next_line(s, nxt); ap.piece(s, trim_eol(s, e)); s = e; }
+                        p = nxt;
+                    }
+                    if (p >= hi && hi < end) {
+                        const char* want = fastq ? fastq_sync(hi, begin, end) : fasta_sync(hi, begin, end);
+                        if (p != want) throw std::runtime_error("malformed " + std::string(fastq ? "FASTQ (four-line records expected)" : "FASTA") + " near byte " + std::to_string((size_t)(hi - begin)) + " of " + path);
+                    }
+                }
+            }
+            ap.flush();
+        } catch (const std::exception& e) {
+            std::lock_guard<std::mutex> l(next_m);
+            if (!failed) { failed = true; first_error = e.what(); }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker, t);
+    for (auto& t : pool) t.join();
+    munmap((void*)data, size);
+    close(fd);
+    if (failed) throw std::runtime_error(first_error);
+}
+
 }  // namespace kqhost

@@ -28,4 +28,16 @@ void read_batches(const std::string& path, size_t batch_bytes, const std::functi
 void read_batches_parallel(const std::string& path, size_t batch_bytes, unsigned threads,
                            const std::function<void(const std::string&)>& on_batch);
 
+// Zero-copy variant for the count path: the parser threads write the sequences straight into buffers the sink hands out
+// (pinned host memory in the CLI) and submit full buffers themselves -- no queue, no consumer thread, no extra copy.
+//   acquire(thread, &cap)     a writable buffer of cap bytes for parser thread `thread` (may block until one is free)
+//   submit(thread, buf, len)  buf holds len bytes of '\n'-separated sequences; the sink owns it again
+// Both are called concurrently from up to `threads` threads (thread ids 0..threads-1); .gz input is inflated and parsed by
+// one thread (id 0).  A single sequence must fit a buffer.
+struct BatchSink {
+    std::function<char*(unsigned thread, size_t* cap)> acquire;
+    std::function<void(unsigned thread, char* buf, size_t len)> submit;
+};
+void read_batches_sink(const std::string& path, unsigned threads, const BatchSink& sink);
+
 }  // namespace kqhost

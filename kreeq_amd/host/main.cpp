@@ -14,6 +14,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -303,16 +304,58 @@ int passes_for(const UserInput& ui, uint64_t distinct) {
     return (int)std::max(1.0, std::min(128.0, std::ceil(table / budget)));
 }
 
-// Read-batch size handed to kq_count_batch: the partitioned count streams the table once per batch, so large
-// inputs (large tables) get batches of up to 1 GiB of bases; small inputs keep 128 MiB for parser/GPU overlap.
-static size_t batch_bytes_for(uint64_t input_bytes) {
-    const uint64_t lo = 128ull << 20, hi = 1ull << 30;
-    return (size_t)std::min(hi, std::max(lo, input_bytes / 16));
-}
 // Memory-bounded validate: the hash maps are processed in `passes` ranges, re-reading the reads for
 // every range -- the GPU counterpart of the reference's map-range loop (computeMapRange /
 // loadMapRange, src/kreeq.cpp:59-74) and of its spill-to-disk behaviour under -m.  Only 1/passes of
 // the table is resident at a time; summary numbers and QV counters add up over the disjoint ranges.
+// Reads -> GPU: every parser thread fills pinned buffers of its own and submits them itself (kq_count_batch_async behind
+// a mutex: the call only enqueues a copy and the count kernels); a thread waits for the copy of a buffer to finish before
+// it refills it.  Parsing, PCIe copies and counting overlap without a consumer thread in between.
+struct GpuSink {
+    kq_handle* h;
+    unsigned threads;
+    size_t cap;
+    struct Slot { char* buf[2] = {nullptr, nullptr}; uint64_t ticket[2] = {0, 0}; bool busy[2] = {false, false}; int cur = 1; };
+    std::vector<Slot> slots;
+    std::mutex m;
+    std::string error;
+    bool pinned;          // page-locked buffers (DMA at PCIe rate, copies overlap everything) pay off from ~1 GB of input: locking pages
+                          // costs about as much as copying them once; below that, plain buffers and staged copies
+    GpuSink(kq_handle* handle, unsigned n_threads, size_t buffer_bytes, bool pin) : h(handle), threads(n_threads), cap(buffer_bytes), slots(n_threads), pinned(pin) {}
+    ~GpuSink() { for (auto& s : slots) for (char* b : s.buf) if (b) { if (pinned) kq_host_free(b); else free(b); } }
+    BatchSink sink() {
+        BatchSink bs;
+        bs.acquire = [this](unsigned t, size_t* c) {
+            Slot& s = slots[t];
+            s.cur ^= 1;
+            if (!s.buf[s.cur]) {
+                s.buf[s.cur] = pinned ? (char*)kq_host_alloc(cap) : (char*)malloc(cap);
+                if (!s.buf[s.cur]) throw std::runtime_error("read buffer allocation failed");
+            }
+            if (s.busy[s.cur]) { if (kq_host_wait(h, s.ticket[s.cur]) != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error()); s.busy[s.cur] = false; }
+            *c = cap;
+            return s.buf[s.cur];
+        };
+        bs.submit = [this](unsigned t, char* buf, size_t len) {
+            Slot& s = slots[t];
+            const int i = buf == s.buf[0] ? 0 : 1;
+            std::lock_guard<std::mutex> l(m);
+            if (kq_count_batch_async(h, buf, len, &s.ticket[i]) != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error());
+            s.busy[i] = true;
+        };
+        return bs;
+    }
+};
+void count_reads_file(kq_handle* h, const std::string& path, unsigned threads, uint64_t input_bytes) {
+    // buffers of 8-32 MiB: small enough that copies and counting of a 300 MB file overlap its parsing, large enough
+    // (>= 7 M k-mers) for the partitioned count path
+    const size_t cap = (size_t)std::min<uint64_t>(32ull << 20, std::max<uint64_t>(8ull << 20, input_bytes / (2 * (uint64_t)threads)));
+    threads = std::min(threads, 64u);                                 // 2 buffers per thread
+    GpuSink gs(h, threads, cap, input_bytes >= (1ull << 30));
+    read_batches_sink(path, threads, gs.sink());
+    kq_or_die(kq_flush(h));                                          // everything is enqueued; the table pass may start
+}
+
 unsigned parser_threads(const UserInput& ui) { return ui.maxThreads > 0 ? (unsigned)ui.maxThreads : std::max(1u, std::thread::hardware_concurrency()); }
 
 int run_passes(Engine& e) {
@@ -341,7 +384,7 @@ int run_passes(Engine& e) {
         if (p) kq_or_die(kq_clear(e.h));
         kq_or_die(kq_set_option(e.h, KQ_OPT_COUNT_MAP_RANGE, (int64_t)lo | ((int64_t)hi << 16)));
         for (auto& f : ui.inReads)
-            read_batches_parallel(f, batch_bytes_for(bytes), threads, [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
+            count_reads_file(e.h, f, threads, bytes);
         kq_stats st;
         kq_or_die(kq_summary(e.h, &st));
         sum.total += st.total; sum.unique += st.unique; sum.distinct += st.distinct; sum.edges += st.edges;
@@ -391,8 +434,7 @@ int run(UserInput& ui) {
                 e.create(distinct_estimate(bytes));
                 verbose("Loading input reads.");
                 for (auto& f : ui.inReads)
-                    read_batches_parallel(f, batch_bytes_for(bytes), parser_threads(ui),
-                                          [&](const std::string& b) { kq_or_die(kq_count_batch(e.h, b.data(), b.size())); });
+                    count_reads_file(e.h, f, parser_threads(ui), bytes);
                 verbose("Reads loaded.");
             } else {                                                 // Input::loadGraph, src/input.cpp:56-74
                 if (ui.kmerDB.size() > 1) die("More than one DBG database provided. Merge them first. Exiting.");
@@ -496,6 +538,32 @@ int main(int argc, char** argv) {
                     }
                 };
                 if (threads == 0) read_batches(argv[3], batch, eat); else read_batches_parallel(argv[3], batch, threads, eat);
+                printf("%llu %llu %llu\n", n, bases, digest);
+                return EXIT_SUCCESS;
+            }
+            if (argc >= 6 && std::string(argv[2]) == "seqsink") {      // the same digest through the zero-copy sink reader (plain heap buffers)
+                const unsigned threads = (unsigned)atoi(argv[4]);
+                const size_t cap = (size_t)atoll(argv[5]);
+                unsigned long long n = 0, bases = 0, digest = 0;
+                std::mutex m;
+                std::vector<std::vector<char>> bufs(std::max(1u, threads));
+                BatchSink sink;
+                sink.acquire = [&](unsigned t, size_t* c) { bufs[t].resize(cap); *c = cap; return bufs[t].data(); };
+                sink.submit = [&](unsigned, char* b, size_t len) {
+                    unsigned long long ln = 0, lb = 0, ld = 0;
+                    size_t i = 0;
+                    while (i <= len) {
+                        const char* nl = (const char*)memchr(b + i, '\n', len - i);
+                        const size_t j = nl ? (size_t)(nl - b) : len;
+                        unsigned long long hsh = 1469598103934665603ull;
+                        for (size_t c = i; c < j; ++c) { hsh ^= (unsigned char)b[c]; hsh *= 1099511628211ull; }
+                        ++ln; lb += j - i; ld += hsh;
+                        i = j + 1;
+                    }
+                    std::lock_guard<std::mutex> l(m);
+                    n += ln; bases += lb; digest += ld;
+                };
+                read_batches_sink(argv[3], threads, sink);
                 printf("%llu %llu %llu\n", n, bases, digest);
                 return EXIT_SUCCESS;
             }

@@ -50,7 +50,7 @@ def test_pending_sets_vs_oracle(kq, O, k, hint, pending):
     if pending == 0:
         assert passes == 5                        # one table pass per batch
     elif pending == -1 and hint:
-        assert passes == 1                        # all five sets in one pass
+        assert passes <= 2                        # the automatic arena starts at a few sets and doubles when it fills up: one or two passes
     elif pending == 12_000_000:
         assert passes == 5                        # the arena holds one set: every new set flushes the previous one
     assert H.entries_equal(gpu.export(), cpu.export())

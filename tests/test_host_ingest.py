@@ -117,3 +117,35 @@ def test_consumer_failure_stops_the_parser_threads(cli, tmp_path):
     r = subprocess.run([cli, "dbtool", "seqsum", gz, "4", "65536"], capture_output=True, text=True,
                        env=dict(os.environ, KQ_TEST_FAIL_AFTER_BATCHES="3"), timeout=60)
     assert r.returncode == 1 and "consumer failed" in r.stderr
+
+
+def test_sink_reader_matches(cli, tmp_path):
+    """read_batches_sink (parser threads write into buffers they submit themselves: the CLI's pinned-memory count path)
+    yields exactly the sequences of the sequential reader -- FASTQ, multi-line FASTA, .gz, small and large buffers"""
+    def seqsink(path, threads, cap):
+        out = subprocess.run([cli, "dbtool", "seqsink", path, str(threads), str(cap)], capture_output=True, text=True, check=True).stdout
+        return tuple(int(x) for x in out.split())
+
+    fq = str(tmp_path / "reads.fastq")
+    want = py_digest(make_fastq(fq, 40000, seed=11))
+    for threads, cap in ((1, 1 << 12), (3, 1 << 14), (8, 1 << 20), (16, 1 << 23)):
+        assert seqsink(fq, threads, cap) == want, (threads, cap)
+    gz = fq + ".gz"
+    with open(fq, "rb") as src, gzip.open(gz, "wb", compresslevel=1) as dst:
+        dst.write(src.read())
+    assert seqsink(gz, 4, 1 << 16) == want
+    rng = np.random.default_rng(12)
+    fa = str(tmp_path / "asm.fasta")
+    seqs = []
+    with open(fa, "wb") as f:
+        for i in range(200):
+            ln = int(rng.integers(1, 50000))
+            s = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), ln))
+            f.write(b">s%d\n" % i)
+            for o in range(0, ln, 60):
+                f.write(s[o:o + 60] + b"\n")
+            seqs.append(s)
+    assert seqsink(fa, 6, 1 << 17) == py_digest(seqs)
+    # a sequence that does not fit a buffer is refused, not truncated
+    r = subprocess.run([cli, "dbtool", "seqsink", fa, "2", "1000"], capture_output=True, text=True)
+    assert r.returncode != 0 and "does not fit" in r.stderr
