@@ -288,3 +288,62 @@ def test_vcf_random_vs_oracle(cli, tmp_path):
     stdout = run(cli, ["validate", "-f", fa, "-r", fq, "-o", out, "--search-depth", "60", "--max-span", "20"])
     assert open(out).read().split("\n")[:-1] == want
     assert stdout[0] == "DBG Summary statistics:"
+
+
+def test_configs4_shape_hifi_k31_vcf(cli, tmp_path):
+    """BASELINE configs[4] shape at small scale: 60x HiFi-length (15 kbp) reads with 0.1 % substitutions, k = 31,
+    validate + candidate-error VCF -- stdout (summary + QV) and VCF equal the oracle's (C oracle for the table and the QV
+    counters, Python restatement for the search).  Read errors are part of the graph (coverage cut-off 0), so the search
+    runs at thousands of branching positions."""
+    import numpy as np
+
+    from oracle import oracle as O
+    from oracle import variants as V
+
+    k = 31
+    rng = np.random.default_rng(31)
+    acgt = "ACGT"
+    comp = str.maketrans("ACGT", "TGCA")
+    genome = "".join(acgt[i] for i in rng.integers(0, 4, 60000))
+    reads = []
+    for s in rng.integers(0, len(genome) - 15000, 240):
+        r = list(genome[s:s + 15000])
+        for p in np.nonzero(rng.random(15000) < 0.001)[0]:
+            r[p] = acgt[(acgt.index(r[p]) + 1 + rng.integers(0, 3)) % 4]
+        r = "".join(r)
+        reads.append(r[::-1].translate(comp) if rng.random() < 0.5 else r)
+    asm = list(genome)
+    for p in sorted(rng.choice(np.arange(500, len(genome) - 500), 25, replace=False), reverse=True):
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            asm[p] = acgt[(acgt.index(asm[p]) + 1 + rng.integers(0, 3)) % 4].lower()
+        elif kind == 1:
+            del asm[p]
+        else:
+            asm.insert(p, acgt[rng.integers(0, 4)].lower())
+    asm = "".join(asm)
+    recs = [("contig1", asm[:35000]), ("contig2", asm[35000:])]
+    fa, fq = str(tmp_path / "asm.fasta"), str(tmp_path / "hifi.fastq")
+    with open(fa, "w") as f:
+        for h, s in recs:
+            f.write(f">{h}\n{s}\n")
+    with open(fq, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(f"@m{i}\n{r}\n+\n{'~' * len(r)}\n")
+    db = O.OracleDB(k, 128)
+    db.count_batch("\n".join(reads).encode(), threads=8)
+    # validate: summary + QV text
+    out = run(cli, ["validate", "-f", fa, "-r", fq, "-k", str(k)])
+    ctr = np.zeros(3, dtype=np.uint64)
+    for _, s in recs:
+        c, _ = db.validate_sequence(s.encode())
+        ctr += c
+    want = H.stats_block(db.summary()) + H.qv_block(int(ctr[0]), int(ctr[1]), int(ctr[2]), k, O.error_rate, O.qv)
+    assert [l for l in out if l] == want
+    # candidate errors
+    got = run(cli, ["validate", "-f", fa, "-r", fq, "-k", str(k), "-o", "vcf", "--search-depth", "40", "--max-span", "16"])
+    while got and got[-1] == "":
+        got.pop()
+    want_vcf = V.correct_sequences(V.Graph(db.export(), k), recs, 40, 16)
+    assert len(want_vcf) > 4 + 20
+    assert got == want_vcf
