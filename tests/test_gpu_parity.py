@@ -853,3 +853,45 @@ def test_sharded5_emit_exchange_insert(kq, O, k, hint, n_parts, n_peers):
         assert np.array_equal(got["cov"], 2 * mine["cov"]) and np.array_equal(got["fw"], 2 * mine["fw"]) and np.array_equal(got["bw"], 2 * mine["bw"])
         total += len(got)
     assert total == len(want)
+
+
+def test_pipelined_host_ingest(kq, O):
+    """kq_count_batch_async + kq_host_alloc / kq_host_wait (the CLI's ingest path for large inputs): batches in pinned
+    buffers, copies on the copy stream into the ring of device staging buffers, counts behind them; two buffers are reused
+    round-robin after waiting for their tickets.  The table must equal the oracle's."""
+    import ctypes as C
+
+    from kreeq_amd import capi
+
+    L = capi.load()
+    k = 21
+    batches = [H.synth_reads(9000 + 400 * i, 150, 200_000, seed=700 + i, err=0.01, n_rate=0.002)[0] for i in range(7)]
+    cpu = O.OracleDB(k, 128)
+    for b in batches:
+        cpu.count_batch(b, threads=8)
+    gpu = kq.KreeqDB(k, 128, capacity_hint=5_000_000)
+    cap = max(len(b) for b in batches)
+    bufs = [L.kq_host_alloc(cap) for _ in range(2)]
+    assert all(bufs)
+    tickets = [None, None]
+    try:
+        for i, b in enumerate(batches):
+            j = i % 2
+            if tickets[j] is not None:
+                gpu.host_wait(tickets[j])                # the copy out of this buffer has finished: it may be refilled
+            C.memmove(bufs[j], b, len(b))
+            tickets[j] = gpu.count_batch_async(bufs[j], len(b))
+        # a pageable buffer works too (staged copy)
+        extra, _ = H.synth_reads(5000, 150, 200_000, seed=790, err=0.01)
+        arr = np.frombuffer(extra, dtype=np.uint8).copy()
+        t = gpu.count_batch_async(arr.ctypes.data, len(arr))
+        gpu.host_wait(t)
+        cpu.count_batch(extra, threads=8)
+        gpu.sync()
+        assert gpu.summary() == cpu.summary()
+        assert H.entries_equal(gpu.export(), cpu.export())
+        with pytest.raises(kq.KqError):
+            gpu.host_wait(10 ** 9)                       # unknown ticket
+    finally:
+        for p in bufs:
+            L.kq_host_free(p)
