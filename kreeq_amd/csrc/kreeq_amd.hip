@@ -1599,7 +1599,27 @@ int kq_export(kq_handle* h, uint16_t map_lo, uint16_t map_hi, kq_entry* out, uin
                 }
             }
             if (!on_device) { (void)hipGetLastError(); src = d_out; }
-            e = hipMemcpy(out, src, n * sizeof(kq_entry), hipMemcpyDeviceToHost);
+            // device -> caller: through two pinned bounce buffers (a copy into pageable memory runs at a fraction of the PCIe
+            // rate: 0.25 s for 850 MB); the DMA of chunk i+1 overlaps the host copy of chunk i
+            const size_t bytes = (size_t)n * sizeof(kq_entry), chunk = (size_t)16 << 20;
+            void* bounce[2] = {nullptr, nullptr};
+            if (bytes > 4 * chunk && hipHostMalloc(&bounce[0], chunk, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&bounce[1], chunk, hipHostMallocDefault) == hipSuccess) {
+                e = hipSuccess;
+                const size_t n_chunks = (bytes + chunk - 1) / chunk;
+                auto len_of = [&](size_t c) { return std::min(chunk, bytes - c * chunk); };
+                e = hipMemcpyAsync(bounce[0], (const char*)src, len_of(0), hipMemcpyDeviceToHost, h->stream);
+                for (size_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+                    e = hipStreamSynchronize(h->stream);
+                    if (e == hipSuccess && c + 1 < n_chunks)
+                        e = hipMemcpyAsync(bounce[(c + 1) & 1], (const char*)src + (c + 1) * chunk, len_of(c + 1), hipMemcpyDeviceToHost, h->stream);
+                    memcpy((char*)out + c * chunk, bounce[c & 1], len_of(c));
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            } else {
+                (void)hipGetLastError();
+                e = hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost);
+            }
+            for (void* b : bounce) if (b) (void)hipHostFree(b);
             if (e != hipSuccess) rc = fail(KQ_ERR_HIP, "export copy failed: %s", hipGetErrorString(e));
             else if (!on_device) parallel_sort_entries(out, n);
             for (void* q : {(void*)d_sorted, (void*)d_k1, (void*)d_k2, (void*)d_i1, (void*)d_i2, d_tmp}) if (q) (void)hipFree(q);

@@ -189,7 +189,7 @@ void write_db_maps(const std::string& db, int map_count, int map_lo, int map_hi,
     // bucket the entries by map in two parallel passes (count per chunk, then fill at the prefix offsets)
     const size_t n_maps = (size_t)(map_hi - map_lo), n = entries.size();
     unsigned hw0 = std::thread::hardware_concurrency();
-    const size_t nt0 = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, hw0 ? hw0 : 1), n / 65536 + 1));
+    const size_t nt0 = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(64, hw0 ? hw0 : 1), n / 65536 + 1));
     std::vector<std::vector<uint64_t>> cnt(nt0, std::vector<uint64_t>(n_maps, 0));
     std::vector<uint64_t> hc_cnt(nt0, 0);
     std::atomic<bool> bad{false};
@@ -242,7 +242,7 @@ void write_db_maps(const std::string& db, int map_count, int map_lo, int map_hi,
     }
     // one file per map: independent, so write them with a few threads
     unsigned hw = std::thread::hardware_concurrency();
-    const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
+    const unsigned nt = std::max(1u, std::min(64u, hw ? hw : 1u));
     std::atomic<int> next{map_lo};
     std::mutex err_m;
     std::string err;
