@@ -140,11 +140,12 @@ def run_human(args, dev, world=1, rank=0):
     db.set_option("count_path", args.path)
     # pending-set arena: the library's automatic arena starts small and doubles when it fills up (a short job never pays
     # for tens of GB of hipMalloc); a job that knows it is long sizes it once, here to the automatic ceiling: a few times
-    # the table, at most half of the HBM that is free now -- allocated by the first warm-up step, outside the timed region
+    # the table, at most the HBM that is free now less 1/8 of the device -- allocated by the first warm-up step, outside the timed region
     pending = args.pending_bytes
     if pending == -1:
         from kreeq_amd.capi import device_memory
-        pending = int(min(device_memory(dev.index)[0] // 2, 4 * db.info()["table_bytes"]))
+        free_b, total_b = device_memory(dev.index)
+        pending = int(min(free_b - total_b // 8 if free_b > total_b // 4 else free_b // 2, 4 * db.info()["table_bytes"]))
     db.set_option("pending_bytes", pending)
 
     def barrier():

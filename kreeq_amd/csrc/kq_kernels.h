@@ -395,10 +395,12 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                                                            const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
                                                            const unsigned long long* __restrict__ group_base, uint64_t* __restrict__ out,
                                                            uint8_t* __restrict__ out_aux) {
-    constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, CONVERT = FMT == FMT_PACK8_TO_NARROW, TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
-    constexpr int MS_FMT = CONVERT ? FMT_NARROW : TOP8 ? FMT_PACK8 : FMT;                  // format of the records this kernel writes
+    constexpr bool WIDE = FMT == FMT_WIDE, TIGHT = FMT == FMT_NARROW_TO_TIGHT, NARROW = FMT == FMT_NARROW || TIGHT, CONVERT = FMT == FMT_PACK8_TO_NARROW,
+                   TOP8 = FMT == FMT_TOP8, HAS_AUX = WIDE || NARROW;
+    constexpr int MS_FMT = (CONVERT || TIGHT) ? FMT_NARROW : TOP8 ? FMT_PACK8 : FMT;       // format of the records this kernel stages
     const uint32_t* recs32 = reinterpret_cast<const uint32_t*>(recs);
     __shared__ MsShared<NBC, MS_FMT, LV_TILE> s;
+    __shared__ uint32_t s_rst[TIGHT ? NBC : 1];     // TIGHT (last level, bin = region): rstart[] of the segment's regions
     const uint32_t nb = lv.nb;
     const uint64_t n_units = unit_base[lv.n_seg];
     const uint32_t n_lseg = lv.n_seg / lv.spb;
@@ -409,6 +411,10 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
         const uint64_t hi = lo + P2_UNIT < seg_hi[b_in] ? lo + P2_UNIT : seg_hi[b_in];
         for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS)
             s.gbase[i] = (uint32_t)(group_base[lv.own_parts ? (uint64_t)i * n_lseg + b : (uint64_t)b * nb + i] + m2[u * nb + i]);
+        if (TIGHT) {
+            const uint32_t first = (b >> lv.nr_shift) * lv.nr_rps + (b & ((1u << lv.nr_shift) - 1u)) * lv.nr_sub;      // narrow_bin's origin; nr_div == 1
+            for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS) s_rst[i] = lv.rstart[first + i];
+        }
 #ifdef KQ_MS_STAMPS
         if (threadIdx.x == 0) { s.stamp_on = 1; s.stamp_last = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -437,7 +443,11 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                 const uint64_t i = pos + (uint64_t)j * LV_THREADS + threadIdx.x;
                 rec[j] = (WIDE && lv.in_raw) ? table_hash(nxt[j], lv.k) : nxt[j];      // raw keys become hashes at the first level
                 aux[j] = nxt_aux[j];
-                if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : lv.own_parts ? owner_bin(lv, b, (uint32_t)rec[j], aux[j]) : narrow_bin(lv, b, (uint32_t)rec[j]));
+                if (TIGHT) {
+                    const uint32_t bn = i >= hi ? nb : narrow_bin(lv, b, (uint32_t)rec[j]);
+                    rec[j] = narrow_word(tight_rec(b >> lv.nr_shift, (uint32_t)rec[j], aux[j], s_rst[bn < nb ? bn : 0u]), 0u, bn);
+                }
+                else if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : lv.own_parts ? owner_bin(lv, b, (uint32_t)rec[j], aux[j]) : narrow_bin(lv, b, (uint32_t)rec[j]));
                 else if (CONVERT) {
                     const uint64_t hh = rec_hash<false>(rec[j]);
                     rec[j] = narrow_word(narrow_main(hh), narrow_aux(hh, (uint32_t)(rec[j] >> REC_EDGE_SHIFT) & 63u), i >= hi ? nb : (uint32_t)(hh >> (64 - NARROW_CBITS)));
@@ -593,6 +603,8 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) n_recs += __shfl_xor(n_recs, o, 64);
         const uint32_t narrow_bucket = (NARROW || TOP8) ? (uint32_t)r / narrow_rps : 0u;
+        const bool tight = NARROW && aux_fmt == AUX_TIGHT;              // FMT_TIGHT sets: one u32 relative to rstart[r], no lockstep byte
+        const uint32_t start_r = tight ? t.rstart[r] : 0u;
         if (n_recs == 0) {                                              // block-uniform
             if (!HOT && table_is_empty == 2) {    // lazy kq_clear: this launch initialises every region, also the ones without records
                 ulonglong2* g2 = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
@@ -735,7 +747,7 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             for (int qq = 0; qq < PF; ++qq) {
                 const uint64_t j = lo_q + min(off + (uint32_t)qq * 64u + lane, cnt - 1u);      // unconditional, index clamped
                 nxt_rec[qq] = NARROW ? (uint64_t)ld_global(reinterpret_cast<const uint32_t*>(rp) + j) : ld_global(rp + j);
-                nxt_aux[qq] = HAS_AUX ? ld_global(ap + j) : 0u;
+                nxt_aux[qq] = (HAS_AUX && !tight) ? ld_global(ap + j) : 0u;
             }
         };
         uint32_t g_cur = tid >> 6;
@@ -757,10 +769,11 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
             const uint64_t rec = cur_rec[q];
             const uint32_t aux = cur_aux[q];
             uint64_t pack = 0;
-            const uint64_t h = NARROW ? narrow_hash(narrow_bucket, (uint32_t)rec, aux) : TOP8 ? top8_hash(narrow_bucket, rec) : rec_hash<WIDE>(rec);
+            const uint64_t h = NARROW ? (tight ? tight_hash((uint32_t)rec, start_r) : narrow_hash(narrow_bucket, (uint32_t)rec, aux))
+                             : TOP8 ? top8_hash(narrow_bucket, rec) : rec_hash<WIDE>(rec);
             const uint64_t key = h;                                          // identity of the k-mer inside this kernel: its hash (a bijection of the key)
             if (active) {
-                pack = NARROW ? s_lut[(aux >> 2) & 63u] : TOP8 ? s_lut[(uint32_t)rec & 63u]
+                pack = NARROW ? s_lut[tight ? (uint32_t)rec & 63u : (aux >> 2) & 63u] : TOP8 ? s_lut[(uint32_t)rec & 63u]
                      : WIDE ? (aux_fmt == AUX_IDX6 ? idx6_to_pack(aux) : edge_byte_to_pack(aux)) : rec_edge_pack(rec);
             }
             const uint64_t act = FOLD ? __ballot(active) : 0ull;
@@ -839,7 +852,8 @@ constexpr uint32_t N32_EMPTY = 0xFFFFFFFFu, N32_TOMB = 1u << 31;
 #ifndef KQ_N32_OCC
 #define KQ_N32_OCC 6
 #endif
-template <int KC>
+// TIGHT: the sets hold FMT_TIGHT records (one u32 = key << 6 | edge indices, no lockstep byte).
+template <int KC, bool TIGHT>
 __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(TableView t, const P3Set* __restrict__ sets, uint32_t n_sets, int table_is_empty,
                                                                       unsigned long long* __restrict__ hot_list, uint32_t rps) {
     constexpr int PF = KQ_P3_PF;
@@ -875,6 +889,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(Ta
         const uint32_t bucket = (uint32_t)r / rps;
         const uint32_t start_r = t.rstart[r];
         const uint32_t top_base = (bucket << (32 - NARROW_CBITS)) - start_r;       // (top 32 hash bits of a record) - rstart[r] = top_base + (u32 >> 8)
+        const uint32_t start_lo = start_r << 10;                                   // TIGHT: key + start_lo = the low 32 bits of (top 32 bits | 10 below)
         if (tid < HC_LDS) {
             s_hckey[tid] = EMPTY_KEY;
 #pragma unroll
@@ -938,7 +953,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(Ta
             for (int qq = 0; qq < PF; ++qq) {
                 const uint64_t j = lo_q + min(off + (uint32_t)qq * 64u + lane, cnt - 1u);
                 nxt_rec[qq] = ld_global(rp + j);
-                nxt_aux[qq] = ld_global(ap + j);
+                nxt_aux[qq] = TIGHT ? 0u : ld_global(ap + j);
             }
         };
         uint32_t g_cur = tid >> 6;
@@ -958,10 +973,11 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(Ta
                 const bool active = (uint32_t)q * 64u + lane < n_cur;
                 const uint32_t m = cur_rec[q], aux = cur_aux[q];
                 const uint32_t low = ((m & 0xFFu) << 2) | (aux & 3u);   // the 10 hash bits below the top 32
-                const uint32_t key = ((top_base + (m >> 8)) << 10) | low;
-                uint32_t pos = KC == 21 ? (((m << 2) | (aux & 3u)) & (REGION_SLOTS - 1))
+                const uint32_t key = TIGHT ? m >> 6 : ((top_base + (m >> 8)) << 10) | low;
+                uint32_t pos = TIGHT ? (((key + start_lo) >> off_shift) & (REGION_SLOTS - 1))          // off_shift + 11 <= 32 (k >= 11)
+                             : KC == 21 ? (((m << 2) | (aux & 3u)) & (REGION_SLOTS - 1))
                                         : (uint32_t)(((((uint64_t)bucket << 34) | ((uint64_t)m << 2) | (aux & 3u)) >> off_shift) & (REGION_SLOTS - 1));
-                const uint64_t pack = s_lut[(aux >> 2) & 63u];
+                const uint64_t pack = s_lut[TIGHT ? m & 63u : (aux >> 2) & 63u];
                 // find-or-claim: two slots of the probe sequence per LDS round trip; one CAS site
                 uint32_t slot = active ? REGION_SLOTS : 0u;             // REGION_SLOTS = still looking
                 uint32_t probes = 0;

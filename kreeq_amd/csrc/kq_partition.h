@@ -27,7 +27,7 @@ constexpr int SEG_MAX = 65536;                   // segments of one split level 
 constexpr uint32_t SUB_BITS_MAX = 8;
 constexpr int REC_EDGE_SHIFT = 56;
 constexpr int PART_MAX_K = 28;                   // packed 8-byte records up to here, WIDE above
-constexpr int AUX_IDX6 = 0, AUX_EDGE_BYTE = 1;
+constexpr int AUX_IDX6 = 0, AUX_EDGE_BYTE = 1, AUX_TIGHT = 2;    // AUX_TIGHT: FMT_TIGHT sets (no lockstep array at all)
 
 struct PartCfg {
     uint64_t n_regions;   // R
@@ -73,6 +73,7 @@ struct LevelCfg {
     //                of a bucket contiguous inside it (send side)
     uint32_t spb, own_parts, map_count, map_mask;
     uint32_t rep_shift;     // rank replication of the multisplit (block_multisplit's rs), set by the host from nb
+    const uint32_t* rstart = nullptr; // non-null: this (last, narrow) level writes FMT_TIGHT records relative to rstart[region]
 };
 __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, uint64_t region) {
     return (uint32_t)(region >> lv.out_shift) - (lv.seg_shift >= 32 ? 0u : (b << (lv.seg_shift - lv.out_shift)));
@@ -124,6 +125,19 @@ constexpr uint32_t NARROW_CBITS = 8, NARROW_MAX_K = 21;
 // left-aligned, | the two edge indices in the low 6 bits.  Replaces the 9-byte WIDE records on the count and
 // lookup paths; split levels and region kernels address it like a narrow record whose u32 is the top half.
 constexpr int FMT_TOP8 = 4;
+// FMT_TIGHT (k <= 21, tables of >= 2^16 regions; the LAST level's output and the pending sets of the count path only): one
+// u32, no lockstep byte.  A record that has reached its region r needs only the hash bits r does not imply:
+//   (top 32 hash bits - rstart[r]) << 16 | the 10 hash bits below << 6 | the two edge indices
+// (ceil(2^32 / R) <= 2^16 values of the first field).  `>> 6` is the 32-bit key of k_count_regions_n32.  4 bytes instead of
+// 5 in the arena, one store per record instead of two in the last level, one load in the table pass.
+constexpr int FMT_TIGHT = 5;
+constexpr int FMT_NARROW_TO_TIGHT = 6;      // k_lv_scatter only: narrow records in, tight records out (last level)
+constexpr uint64_t TIGHT_MIN_REGIONS = 1ull << 16;
+__device__ __forceinline__ uint32_t tight_rec(uint32_t bucket, uint32_t main32, uint32_t aux, uint32_t rstart_r) {
+    const uint32_t d = ((bucket << (32 - NARROW_CBITS)) | (main32 >> NARROW_CBITS)) - rstart_r;
+    return (d << 16) | ((main32 & 0xFFu) << 8) | ((aux & 3u) << 6) | (aux >> 2);
+}
+__device__ __forceinline__ uint64_t tight_hash(uint32_t t, uint32_t rstart_r) { return ((uint64_t)((t >> 16) + rstart_r) << 32) | ((uint64_t)((t >> 6) & 1023u) << 22); }
 __device__ __forceinline__ uint64_t top8_rec(uint64_t h, uint32_t idx6) { return ((h << NARROW_CBITS) & ~63ull) | idx6; }
 __device__ __forceinline__ uint64_t top8_hash(uint32_t bucket, uint64_t rec) { return ((uint64_t)bucket << (64 - NARROW_CBITS)) | ((rec & ~63ull) >> NARROW_CBITS); }
 __device__ __forceinline__ uint32_t narrow_main(uint64_t h) { return (uint32_t)(h >> (32 - NARROW_CBITS)); }
@@ -271,7 +285,7 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
         if (j < total) {
             if (FMT == FMT_NARROW) {
                 reinterpret_cast<uint32_t*>(out)[cg[it]] = (uint32_t)cv[it];
-                out_aux[cg[it]] = (uint8_t)(cv[it] >> 48);
+                if (out_aux) out_aux[cg[it]] = (uint8_t)(cv[it] >> 48);       // (uniform) FMT_TIGHT output has no lockstep byte
             } else {
                 out[cg[it]] = cv[it];
                 if (FMT == FMT_WIDE) out_aux[cg[it]] = s.saux[j];

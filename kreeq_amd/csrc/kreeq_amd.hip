@@ -657,6 +657,7 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
                                         p->seg_off, seg_hi, p->unit_base, p->m2, gb, out, out_aux)
     if (lv.top8)              { KQ_LVS(FMT_PACK8_TO_NARROW, 512); }
     else if (fmt == FMT_TOP8) { if (small) KQ_LVS(FMT_TOP8, 512); else KQ_LVS(FMT_TOP8, NB_MAX); }
+    else if (fmt == FMT_NARROW && lv.rstart) { if (small) KQ_LVS(FMT_NARROW_TO_TIGHT, 512); else KQ_LVS(FMT_NARROW_TO_TIGHT, NB_MAX); }
     else if (fmt == FMT_NARROW) { if (small) KQ_LVS(FMT_NARROW, 512); else KQ_LVS(FMT_NARROW, NB_MAX); }
     else if (fmt == FMT_WIDE) { if (small) KQ_LVS(FMT_WIDE, 512); else KQ_LVS(FMT_WIDE, NB_MAX); }
     else                      { if (small) KQ_LVS(FMT_PACK8, 512); else KQ_LVS(FMT_PACK8, NB_MAX); }
@@ -685,7 +686,15 @@ static LevelCfg level_narrow(const PartCfg& cfg, uint32_t sub_bits = 0, bool mid
 }
 // bucket -> regions for FMT_NARROW records, in one level or (large tables) two; afterwards `*sorted` holds the
 // records grouped by region and p->group_base their offsets
-static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux, const P3Set* dst = nullptr);
+static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux, const P3Set* dst = nullptr, bool tight = false);
+// FMT_TIGHT output of the last split level (count path only: the lookup kernels read 5-byte records)
+static bool tight_ok(const kq_handle* h, const PartPlan& p) {
+#ifdef KQ_NO_TIGHT
+    (void)h; (void)p; return false;
+#else
+    return p.fmt == FMT_NARROW && p.R >= TIGHT_MIN_REGIONS && h->rstart != nullptr;
+#endif
+}
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
@@ -703,7 +712,7 @@ static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
 __global__ void k_p3set(P3Set* sets, int i, P3Set v) { sets[i] = v; }
 
 static size_t set_bytes(uint64_t n_max, int fmt, uint64_t R) {
-    const size_t rec = fmt == FMT_NARROW ? 4 : 8;
+    const size_t rec = (fmt == FMT_NARROW || fmt == FMT_TIGHT) ? 4 : 8;
     const bool aux = fmt == FMT_NARROW || fmt == FMT_WIDE;
     return ((((size_t)n_max * rec + 63) & ~(size_t)63) + (aux ? (((size_t)n_max + 63) & ~(size_t)63) : 0) + (size_t)(R + 2) * 8 + 255) & ~(size_t)255;
 }
@@ -718,8 +727,8 @@ static int arena_take(kq_handle* h, uint64_t n_max, int fmt, uint64_t R, P3Set* 
         int rc = flush_pending(h);
         if (rc) return rc;
     }
-    // The arena starts at a few sets and doubles every time it fills up, up to a few times the table and half of what is
-    // free (a fixed KQ_OPT_PENDING_BYTES is taken as it is): a short job never pays for allocating tens of GB (hipMalloc
+    // The arena starts at a few sets and doubles every time it fills up, up to a few times the table and what is free less
+    // a reserve (a fixed KQ_OPT_PENDING_BYTES is taken as it is): a short job never pays for allocating tens of GB (hipMalloc
     // costs milliseconds per GB), a long one gets there within its first batches
     size_t want = h->arena_bytes;
     if (need > want) want = h->pend_budget > 0 ? (size_t)h->pend_budget : std::max<size_t>(4 * need, (size_t)64 << 20);
@@ -728,7 +737,11 @@ static int arena_take(kq_handle* h, uint64_t n_max, int fmt, uint64_t R, P3Set* 
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return KQ_OK;
         size_t budget = want;
-        if (h->pend_budget < 0) budget = std::min<size_t>(want, std::min<size_t>((free_b + h->arena_bytes) / 2, std::max<size_t>(4 * need, 4 * (size_t)h->n_slots() * sizeof(Slot))));
+        // ceiling: what is free now (the partition scratch of this slice size is allocated already) less a reserve of 1/8 of
+        // the device for whatever comes later (side-table growth, lookup / export buffers); half of it when that is tight
+        const size_t avail = free_b + h->arena_bytes, reserve = std::max<size_t>(total_b / 8, (size_t)8 << 30);
+        const size_t ceiling = avail > 2 * reserve ? avail - reserve : avail / 2;
+        if (h->pend_budget < 0) budget = std::min<size_t>(want, std::min<size_t>(ceiling, std::max<size_t>(4 * need, 4 * (size_t)h->n_slots() * sizeof(Slot))));
         if (budget <= h->arena_bytes && need <= h->arena_bytes) budget = 0;         // at its ceiling already
         if (budget && budget < need) return KQ_OK;
         if (budget) {
@@ -738,7 +751,7 @@ static int arena_take(kq_handle* h, uint64_t n_max, int fmt, uint64_t R, P3Set* 
         }
     }
     uint8_t* base = (uint8_t*)h->arena + h->arena_used;
-    const size_t rec = fmt == FMT_NARROW ? 4 : 8;
+    const size_t rec = (fmt == FMT_NARROW || fmt == FMT_TIGHT) ? 4 : 8;
     const bool aux = fmt == FMT_NARROW || fmt == FMT_WIDE;
     out->recs = (const uint64_t*)base;
     base += ((size_t)n_max * rec + 63) & ~(size_t)63;
@@ -781,17 +794,19 @@ static int flush_pending(kq_handle* h) {
     // also write the image of regions without records.  A dirty array is never read, whatever table_empty says
     const int empty = h->slots_dirty ? 2 : h->table_empty ? 1 : 0;
     const int fmt = h->pend_fmt;
-    const uint32_t rps = (fmt == FMT_NARROW || fmt == FMT_TOP8) ? (uint32_t)(R >> NARROW_CBITS) : 1u;
+    const uint32_t rps = (fmt == FMT_NARROW || fmt == FMT_TIGHT || fmt == FMT_TOP8) ? (uint32_t)(R >> NARROW_CBITS) : 1u;
 #define KQ_P3(F) do { \
         hipLaunchKernelGGL((k_count_regions<F, false>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, h->pend_aux_fmt, empty, hot, rps); \
         hipLaunchKernelGGL((k_count_regions<F, true>), grid_hot, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, h->pend_aux_fmt, empty, hot, rps); } while (0)
 #ifdef KQ_NO_N32
-    if (fmt == FMT_NARROW) KQ_P3(FMT_NARROW); else
+    if (fmt == FMT_NARROW || fmt == FMT_TIGHT) KQ_P3(FMT_NARROW); else      // (pend_aux_fmt == AUX_TIGHT tells the generic kernel about FMT_TIGHT sets)
 #endif
-    if (fmt == FMT_NARROW) {
+    if (fmt == FMT_NARROW || fmt == FMT_TIGHT) {
         // ordinary regions: the compact 32-bit-key kernel; skewed ones: the generic folding kernel
-        if (h->k == 21) hipLaunchKernelGGL((k_count_regions_n32<21>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps);
-        else hipLaunchKernelGGL((k_count_regions_n32<0>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps);
+#define KQ_N32(KC, T) hipLaunchKernelGGL((k_count_regions_n32<KC, T>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps)
+        if (fmt == FMT_TIGHT) { if (h->k == 21) KQ_N32(21, true); else KQ_N32(0, true); }
+        else                  { if (h->k == 21) KQ_N32(21, false); else KQ_N32(0, false); }
+#undef KQ_N32
         hipLaunchKernelGGL((k_count_regions<FMT_NARROW, true>), grid_hot, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, h->pend_aux_fmt, empty, hot, rps);
     }
     else if (fmt == FMT_TOP8) KQ_P3(FMT_TOP8);
@@ -818,20 +833,22 @@ static bool part_table_ok(const kq_handle* h, bool narrow_possible) {
     return c.narrow != 0;
 }
 // `dst` != nullptr: the last level writes records, lockstep bytes and region offsets there (a pending set in the arena)
-static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux, const P3Set* dst) {
+static void run_narrow_levels(kq_handle* h, PartPlan* p, const uint64_t** sorted, const uint8_t** sorted_aux, const P3Set* dst, bool tight) {
     const uint32_t sb = p->cfg.sub_bits;
     const bool t8 = p->fmt == FMT_TOP8;
     uint8_t* a1 = t8 ? nullptr : p->aux1;
     uint8_t* a2 = t8 ? nullptr : p->aux2;
     uint64_t* fin = dst ? const_cast<uint64_t*>(dst->recs) : (sb == 0 ? p->recs2 : p->recs1);
-    uint8_t* fin_aux = t8 ? nullptr : dst ? const_cast<uint8_t*>(dst->aux) : (sb == 0 ? a2 : a1);
+    uint8_t* fin_aux = (t8 || tight) ? nullptr : dst ? const_cast<uint8_t*>(dst->aux) : (sb == 0 ? a2 : a1);
     unsigned long long* fin_base = dst ? const_cast<unsigned long long*>(dst->base) : p->group_base;
+    LevelCfg last = level_narrow(p->cfg, sb, false, t8);
+    if (tight) last.rstart = h->rstart;
     if (sb == 0) {
-        run_level(h, p, level_narrow(p->cfg, 0, false, t8), p->recs1, a1, fin, fin_aux, fin_base);
+        run_level(h, p, last, p->recs1, a1, fin, fin_aux, fin_base);
     } else {
         run_level(h, p, level_narrow(p->cfg, sb, true, t8), p->recs1, a1, p->recs2, a2);
         (void)hipMemcpyAsync(p->seg_off, p->group_base, (size_t)(((1u << NARROW_CBITS) << sb) + 1) * 8, hipMemcpyDeviceToDevice, h->stream);
-        run_level(h, p, level_narrow(p->cfg, sb, false, t8), p->recs2, a2, fin, fin_aux, fin_base);
+        run_level(h, p, last, p->recs2, a2, fin, fin_aux, fin_base);
     }
     *sorted = fin; *sorted_aux = fin_aux;
 }
@@ -858,13 +875,15 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     p.cfg.filt_lo = h->filt_lo; p.cfg.filt_hi = h->filt_hi;      // KQ_OPT_COUNT_MAP_RANGE
     const bool leveled = p.fmt == FMT_NARROW || p.fmt == FMT_TOP8 || p.two_level;
     P3Set set; bool in_arena = false;
-    if (leveled) { rc = arena_take(h, p.n_max, p.fmt, p.R, &set, &in_arena); if (rc) return rc; }
+    const bool tight = tight_ok(h, p);
+    const int set_fmt = tight ? FMT_TIGHT : p.fmt;
+    if (leveled) { rc = arena_take(h, p.n_max, set_fmt, p.R, &set, &in_arena); if (rc) return rc; }
     marks_reset(h);
     mark(h, "start");
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
     if (p.fmt == FMT_NARROW || p.fmt == FMT_TOP8) {
         const uint64_t* sorted; const uint8_t* sorted_aux;
-        run_narrow_levels(h, &p, &sorted, &sorted_aux, in_arena ? &set : nullptr);
+        run_narrow_levels(h, &p, &sorted, &sorted_aux, in_arena ? &set : nullptr, tight);
         if (!in_arena) set = P3Set{sorted, sorted_aux, p.group_base, p.n_max};
     } else if (p.two_level) {
         if (in_arena) run_level(h, &p, level_coarse_to_regions(p.cfg), p.recs1, a1, const_cast<uint64_t*>(set.recs), const_cast<uint8_t*>(set.aux), const_cast<unsigned long long*>(set.base));
@@ -873,7 +892,7 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
         set = P3Set{p.recs1, a1, p.seg_off, p.n_max};          // bins were the regions themselves
     }
     HIPC(hipGetLastError());
-    return pend_or_apply(h, set, p.fmt, AUX_IDX6, in_arena);
+    return pend_or_apply(h, set, set_fmt, tight ? AUX_TIGHT : AUX_IDX6, in_arena);
 }
 // partitioned count of n records already on the device (multi-GPU receive side, kq_insert_records_dev).
 // d_aux == nullptr: packed 8-byte records; else WIDE records with d_aux in `aux_fmt`.
@@ -886,17 +905,18 @@ static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const
     if (p.fmt == FMT_NARROW) {
         // packed records of kq_emit_packed_dev on a narrow-eligible table: the first level splits on the top 8 hash
         // bits and writes 5-byte records, the rest is the narrow path of count_partitioned
-        rc = arena_take(h, p.n_max, p.fmt, p.R, &set, &in_arena); if (rc) return rc;
+        const bool tight = tight_ok(h, p);
+        rc = arena_take(h, p.n_max, tight ? FMT_TIGHT : p.fmt, p.R, &set, &in_arena); if (rc) return rc;
         hipLaunchKernelGGL(k_set2, dim3(1), dim3(1), 0, h->stream, p.seg_off, 0ull, (unsigned long long)n);
         LevelCfg first = level_flat_to_coarse(p.cfg);
         first.top8 = 1; first.nb = 1u << NARROW_CBITS;
         run_level(h, &p, first, d_recs, nullptr, p.recs1, p.aux1);
         HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)((1u << NARROW_CBITS) + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
         const uint64_t* sorted; const uint8_t* sorted_aux;
-        run_narrow_levels(h, &p, &sorted, &sorted_aux, in_arena ? &set : nullptr);
+        run_narrow_levels(h, &p, &sorted, &sorted_aux, in_arena ? &set : nullptr, tight);
         if (!in_arena) set = P3Set{sorted, sorted_aux, p.group_base, p.n_max};
         HIPC(hipGetLastError());
-        return pend_or_apply(h, set, FMT_NARROW, AUX_IDX6, in_arena);
+        return pend_or_apply(h, set, tight ? FMT_TIGHT : FMT_NARROW, tight ? AUX_TIGHT : AUX_IDX6, in_arena);
     }
     if (d_aux) p.fmt = FMT_WIDE;
     uint8_t* a1 = d_aux ? p.aux1 : nullptr;
@@ -1229,14 +1249,16 @@ int kq_insert_sharded_dev(kq_handle* h, const uint32_t* d_recs, const uint8_t* d
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, h->stream, start, (uint64_t)n_in, start + n_in);
     hipLaunchKernelGGL(k_sharded_segments, dim3((n_in + 255) / 256), dim3(256), 0, h->stream, start, (const unsigned long long*)d_bucket_counts, (uint32_t)n_peers, seg_lo, seg_hi);
     P3Set set; bool in_arena = false;
-    rc = arena_take(h, p.n_max, p.fmt, p.R, &set, &in_arena); if (rc) return rc;
+    const bool tight = tight_ok(h, p);
+    rc = arena_take(h, p.n_max, tight ? FMT_TIGHT : p.fmt, p.R, &set, &in_arena); if (rc) return rc;
     const uint32_t sb = p.cfg.sub_bits;
     uint64_t* fin = in_arena ? const_cast<uint64_t*>(set.recs) : p.recs2;
-    uint8_t* fin_aux = in_arena ? const_cast<uint8_t*>(set.aux) : p.aux2;
+    uint8_t* fin_aux = tight ? nullptr : in_arena ? const_cast<uint8_t*>(set.aux) : p.aux2;
     unsigned long long* fin_base = in_arena ? const_cast<unsigned long long*>(set.base) : p.group_base;
     unsigned long long* own_seg_off = p.seg_off;
     LevelCfg first = level_narrow(p.cfg, sb, sb != 0);
     first.n_seg = n_in; first.spb = (uint32_t)n_peers;
+    if (tight && sb == 0) first.rstart = h->rstart;               // it is the last level as well
     p.seg_off = seg_lo;                                           // the first level reads the received runs
     if (sb == 0) {
         run_level(h, &p, first, (const uint64_t*)d_recs, d_aux, fin, fin_aux, fin_base, seg_hi);
@@ -1245,12 +1267,14 @@ int kq_insert_sharded_dev(kq_handle* h, const uint32_t* d_recs, const uint8_t* d
         run_level(h, &p, first, (const uint64_t*)d_recs, d_aux, p.recs1, p.aux1, nullptr, seg_hi);
         p.seg_off = own_seg_off;
         HIPC(hipMemcpyAsync(p.seg_off, p.group_base, (size_t)(((1u << NARROW_CBITS) << sb) + 1) * 8, hipMemcpyDeviceToDevice, h->stream));
-        if (!in_arena) { fin = p.recs2; fin_aux = p.aux2; }
-        run_level(h, &p, level_narrow(p.cfg, sb, false), p.recs1, p.aux1, fin, fin_aux, fin_base);
+        if (!in_arena) { fin = p.recs2; fin_aux = tight ? nullptr : p.aux2; }
+        LevelCfg last = level_narrow(p.cfg, sb, false);
+        if (tight) last.rstart = h->rstart;
+        run_level(h, &p, last, p.recs1, p.aux1, fin, fin_aux, fin_base);
     }
     if (!in_arena) set = P3Set{fin, fin_aux, fin_base, p.n_max};
     HIPC(hipGetLastError());
-    return pend_or_apply(h, set, FMT_NARROW, AUX_IDX6, in_arena);
+    return pend_or_apply(h, set, tight ? FMT_TIGHT : FMT_NARROW, tight ? AUX_TIGHT : AUX_IDX6, in_arena);
 }
 
 int kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n) {

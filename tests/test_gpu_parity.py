@@ -809,7 +809,8 @@ def test_lookup_keys_and_branch_scan(kq, O):
         assert flags[c] == f, (c, flags[c], f)
 
 
-@pytest.mark.parametrize("k,hint,n_parts,n_peers", [(21, 5_000_000, 3, 2), (21, 40_000_000, 8, 3), (17, 5_000_000, 2, 1), (21, 5_870_000, 5, 4)])
+@pytest.mark.parametrize("k,hint,n_parts,n_peers", [(21, 5_000_000, 3, 2), (21, 40_000_000, 8, 3), (17, 5_000_000, 2, 1), (21, 5_870_000, 5, 4),
+                                                    (21, 100_000_000, 2, 3)])      # >= 2^16 regions per receiver: FMT_TIGHT pending sets
 def test_sharded5_emit_exchange_insert(kq, O, k, hint, n_parts, n_peers):
     """multi-GPU exchange with 5-byte records, emulated in one process: n_peers senders split their reads by owner part
     (kq_emit_sharded_dev), each of n_parts receivers gets its run from every peer plus the per-bucket counts and inserts

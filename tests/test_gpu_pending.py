@@ -35,7 +35,9 @@ def _batches(n, k, seed, genome=400_000):
 
 # arena sizes: automatic, off, one set at a time (5 MB < two sets of ~1.5 M records x 5 B + offsets), a few sets
 @pytest.mark.parametrize("k,hint,pending", [(21, 5_000_000, -1), (21, 5_000_000, 0), (21, 5_000_000, 12_000_000), (21, 5_000_000, 26_000_000),
-                                            (21, 0, -1), (27, 4_000_000, -1), (31, 5_000_000, -1), (31, 0, 30_000_000), (13, 3_000_000, -1)])
+                                            (21, 0, -1), (27, 4_000_000, -1), (31, 5_000_000, -1), (31, 0, 30_000_000), (13, 3_000_000, -1),
+                                            # tables of >= 2^16 regions: the last level writes 4-byte FMT_TIGHT records
+                                            (21, 100_000_000, -1), (21, 100_000_000, 0), (21, 92_000_000, 26_000_000), (15, 100_000_000, -1), (17, 400_000_000, -1)])
 def test_pending_sets_vs_oracle(kq, O, k, hint, pending):
     gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=hint), O.OracleDB(k, 128)
     gpu.set_option("count_path", "partitioned")
@@ -101,13 +103,13 @@ def test_pending_mixed_with_other_entry_points(kq, O):
     assert H.entries_equal(gpu.export(), c2.export())
 
 
-def test_pending_hot_kmers(kq, O):
+@pytest.mark.parametrize("hint", [5_000_000, 100_000_000])      # 5-byte records / 4-byte FMT_TIGHT records in the pending sets
+def test_pending_hot_kmers(kq, O, hint):
     """skewed regions (homopolymer reads) across several pending sets: the second launch folds them"""
     k = 21
-    rng = np.random.default_rng(5)
     normal = _batches(3, k, seed=77)
     hot = b"\n".join([b"A" * 150] * 9000 + [b"ACGT" * 37 + b"AC"] * 3000)
-    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=5_000_000), O.OracleDB(k, 128)
+    gpu, cpu = kq.KreeqDB(k, 128, capacity_hint=hint), O.OracleDB(k, 128)
     gpu.set_option("count_path", "partitioned")
     for b in (normal[0], hot, normal[1], hot, normal[2]):
         gpu.count_batch(b)
