@@ -123,10 +123,18 @@ void* kq_get_stream(kq_handle* h);
  *                          this many bytes of HBM and applies all pending sets in one pass over the table (when the arena
  *                          is full, and before anything reads the table: kq_sync, summary, lookup, export, merge ...), so
  *                          that a large table is streamed once per arena-full of records rather than once per slice.
- *                          -1 = automatic (default: a few times the table, at most half of the free HBM), 0 = apply every
- *                          slice at once.  Results never depend on it (counting is commutative). */
+ *                          -1 = automatic (default: a few times the table, at most the free HBM less 1/8 of the device),
+ *                          0 = apply every slice at once.  Results never depend on it (counting is commutative).
+ *   KQ_OPT_BUCKET_WINDOW   value = lo | hi << 16, 0 <= lo < hi <= 256, on an EMPTY handle with k <= 21: the handle becomes one
+ *                          shard of a multi-GPU database -- it holds, and answers for, only the k-mers whose table hash
+ *                          starts with one of the 8-bit prefixes ("hash-prefix buckets") lo .. hi-1.  The memory kq_create
+ *                          sized is kept and laid out as that window of a table 256 / (hi - lo) times larger, so the bucket
+ *                          split of the count path is the owner split of the exchange (kq_emit_sharded_dev /
+ *                          kq_insert_sharded_dev).  k-mers of other buckets are ignored by every entry point: counts drop
+ *                          them, lookups do not evaluate them (their sum over the shards is the whole answer, like the map
+ *                          ranges of src/kreeq.cpp:150), export / summary see the window's k-mers. */
 enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4, KQ_OPT_PROFILE = 5,
-       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8, KQ_OPT_PENDING_BYTES = 9,
+       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8, KQ_OPT_PENDING_BYTES = 9, KQ_OPT_BUCKET_WINDOW = 10,
        KQ_OPT_TEST_FAIL_PLAN = 100 /* failure-path tests only: the next partition plan of a count fails with KQ_ERR_NOMEM */ };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_get_profile(kq_handle* h, char* buf, uint64_t cap);
@@ -187,14 +195,18 @@ int  kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_p
                         uint64_t* d_recs, uint64_t cap, uint64_t* part_counts);
 int  kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n);
 
-/* The same staging with 5-BYTE records (k <= 21, the default k): d_recs[i] (u32) + d_aux[i] (u8) = the hash bits below
- * the 8-bit hash-prefix bucket of record i and its two edge indices -- the record format of the single-GPU count.  The
- * part of every owner is one contiguous run (part_counts, host), inside it the records are grouped by bucket:
- * d_bucket_counts[p * 256 + b] (DEVICE, n_parts x 256) = records of bucket b for part p.  The receiver gets, from every
- * peer, its run and that peer's 256 counts for it (one all-to-all(v) per array + one all-to-all of 256 counts) and calls
- * kq_insert_sharded_dev with the runs concatenated in peer order and d_bucket_counts = [n_peers x 256] (DEVICE, peer-
- * major): the records enter the bucket -> region split levels directly.  The receiving table must have >= 2048 regions.
- * Buffers need room for len - k + 1 records.  kq_emit_sharded_dev synchronises. */
+/* Multi-GPU staging with 5-BYTE records (k <= 21, the default k): d_recs[i] (u32) + d_aux[i] (u8) = the hash bits below
+ * the 8-bit hash-prefix bucket of record i and its two edge indices -- the record format of the single-GPU count, written
+ * by its first (bucket) split.  OWNERSHIP IS BY BUCKET RANGE: part p of n_parts owns the buckets
+ * [ceil(256 p / n_parts), ceil(256 (p + 1) / n_parts)), so the bucket-sorted output is already grouped by owner: the part
+ * of every owner is one contiguous run (part_counts, host), and d_bucket_counts[p * 256 + b] (DEVICE, n_parts x 256) =
+ * records of bucket b if p owns it, else 0.  The receiver gets, from every peer, its run and that peer's 256 counts for it
+ * (one all-to-all(v) per array + one all-to-all of 256 counts) and calls kq_insert_sharded_dev with the runs concatenated
+ * in peer order and d_bucket_counts = [n_peers x 256] (DEVICE, peer-major): the records enter the bucket -> region split
+ * levels directly.  The receiving handle is the window of its buckets (KQ_OPT_BUCKET_WINDOW; with one part: an ordinary
+ * table) and must have >= 2048 regions; records of buckets outside its window are ignored.
+ * (The reference's key % mapCount -- src/graph-builder.cpp:95 -- remains the layout of the database FILES: export filters
+ * by map range on every shard.)  Buffers need room for len - k + 1 records.  kq_emit_sharded_dev synchronises. */
 int  kq_emit_sharded_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts, uint32_t* d_recs, uint8_t* d_aux, uint64_t cap,
                          uint64_t* d_bucket_counts, uint64_t* part_counts);
 int  kq_insert_sharded_dev(kq_handle* h, const uint32_t* d_recs, const uint8_t* d_aux, uint64_t n, int n_peers, const uint64_t* d_bucket_counts);

@@ -50,9 +50,14 @@ struct DevState {
     unsigned int pad[2];
 };
 
+// A table may hold only a WINDOW of its regions (multi-GPU shards: the rank that owns the hash-prefix buckets [b_lo, b_hi)
+// allocates the regions [reg_lo, reg_hi) = [b_lo, b_hi) x n_regions / 256 of the common geometry and nothing else).
+// `slots` is the address region 0 WOULD have, so region r of the window is slots + (r << REGION_SHIFT) like everywhere
+// else and no hash -> region computation changes; only loops over the table and accesses by hash look at the window.
 struct TableView {
     Slot* slots;
-    uint64_t n_regions;
+    uint64_t n_regions;     // of the whole geometry (the scale of hash_region)
+    uint64_t reg_lo, reg_hi;   // allocated regions: [0, n_regions) unless the table is a window
     HcSlot* hc;
     uint64_t hc_mask;       // capacity - 1
     DevState* st;
@@ -148,8 +153,14 @@ __device__ __forceinline__ uint64_t ld_relaxed(const uint64_t* p) {
 __device__ __forceinline__ Slot* region_of(const TableView& t, uint64_t h) {
     return t.slots + (hash_region(h, t.n_regions) << REGION_SHIFT);
 }
+// does the table hold the region of hash h?  (always, unless it is a window)
+__device__ __forceinline__ bool table_owns(const TableView& t, uint64_t h) {
+    const uint64_t r = hash_region(h, t.n_regions);
+    return r >= t.reg_lo && r < t.reg_hi;
+}
 
 __device__ __forceinline__ const Slot* table_find(const TableView& t, uint64_t h) {
+    if (!table_owns(t, h)) return nullptr;
     const Slot* base = region_of(t, h);
     const uint64_t rem = slot_rem(h, t.k);
     uint32_t off = hash_offset(h, t.k);
@@ -209,6 +220,7 @@ __device__ __forceinline__ bool hc_add(const TableView& t, uint64_t h, uint64_t 
 // counting its first instance in one step); the tombstone is sticky, so the high-copy tier needs no CAS.
 __device__ __forceinline__ bool table_add(const TableView& t, uint64_t h, uint64_t cov, uint64_t pack8,
                                           const uint32_t* wide /*8 counters or nullptr*/, uint32_t* inserted) {
+    if (!table_owns(t, h)) return false;                               // a window takes only the k-mers of its own buckets
     Slot* base = region_of(t, h);
     const uint64_t rem = slot_rem(h, t.k);
     const uint32_t off = hash_offset(h, t.k);

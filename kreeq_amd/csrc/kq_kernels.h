@@ -591,12 +591,12 @@ __global__ __launch_bounds__(P3_THREADS, HOT ? 4 : KQ_P3_OCC) void k_count_regio
     __shared__ uint64_t s_hckey[HC_LDS];
     __shared__ uint32_t s_hccnt[HC_LDS][8];
     const int tid = threadIdx.x;
-    const uint64_t n_work = HOT ? hot_list[0] : t.n_regions;
+    const uint64_t n_work = HOT ? hot_list[0] : t.reg_hi - t.reg_lo;
 #ifdef KQ_STAMPS
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
     for (uint64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const uint64_t r = HOT ? hot_list[1 + w] : w;
+        const uint64_t r = HOT ? hot_list[1 + w] : t.reg_lo + w;
         SetTickets<(uint32_t)GRP> tk;                                   // this region's share of every set (per wave, in registers)
         tk.build(sets, n_sets, r, (uint32_t)tid & 63u);
         uint64_t n_recs = tk.cnt;                                       // block-uniform after the reduction
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(Ta
     const uint32_t lane = tid & 63;
     const uint32_t k = KC ? KC : t.k;
     const uint32_t off_shift = 42 - 2 * k;                              // k <= 21
-    for (uint64_t r = blockIdx.x; r < t.n_regions; r += gridDim.x) {
+    for (uint64_t r = t.reg_lo + blockIdx.x; r < t.reg_hi; r += gridDim.x) {
         SetTickets<GRP> tk;
         tk.build(sets, n_sets, r, lane);
         uint64_t n_recs = tk.cnt;                                       // block-uniform after the reduction
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(P3_THREADS, 8) void k_lookup_regions(TableView t, c
     __shared__ uint64_t s_img[REGION_SLOTS * 2];                        // the region as it lies in HBM (read-only here): 32 KiB, four workgroups per CU
     const int tid = threadIdx.x;
     uint32_t missing = 0, total = 0, edge_missing = 0;
-    for (uint64_t r = blockIdx.x; r < t.n_regions; r += gridDim.x) {
+    for (uint64_t r = t.reg_lo + blockIdx.x; r < t.reg_hi; r += gridDim.x) {       // (a window evaluates the k-mers of its own buckets only)
         const uint64_t lo = region_base[r], hi = region_base[r + 1];
         if (lo == hi) continue;                                         // block-uniform
         const uint4* gimg = reinterpret_cast<const uint4*>(t.slots + (r << REGION_SHIFT));
@@ -1179,9 +1179,9 @@ __global__ __launch_bounds__(256) void k_import(TableView t, const kq_entry* __r
 __global__ __launch_bounds__(256) void k_merge(TableView dst, TableView src) {
     uint32_t n_new = 0;
     uint64_t n_cov = 0;
-    const uint64_t n = src.n_regions << REGION_SHIFT;
+    const uint64_t s0 = src.reg_lo << REGION_SHIFT, n = (src.reg_hi - src.reg_lo) << REGION_SHIFT;     // the allocated slots
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const Slot* s = src.slots + i;
+        const Slot* s = src.slots + s0 + i;
         const uint64_t w0 = s->w0;
         if (w0 == 0) continue;
         const uint64_t h = slot_hash_at(src, s, w0);
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, 
     uint32_t n_new = 0;
     uint64_t n_cov = 0;
     constexpr int SPT = REGION_SLOTS / P3_THREADS;
-    for (uint64_t r = blockIdx.x; r < dst.n_regions; r += gridDim.x) {
+    for (uint64_t r = dst.reg_lo + blockIdx.x; r < dst.reg_hi; r += gridDim.x) {
         ulonglong2* gimg = reinterpret_cast<ulonglong2*>(dst.slots + (r << REGION_SHIFT));
         if (dst_is_empty) {
             for (int i = tid; i < (int)(REGION_SLOTS * 3); i += P3_THREADS) s_img[i] = (i % 3 == 0) ? EMPTY_KEY : 0ull;
@@ -1220,8 +1220,10 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, 
         // hash interval of dst region r (top 32 bits): [ceil(r 2^32 / R), ceil((r+1) 2^32 / R) - 1]
         const uint64_t R = dst.n_regions;
         const uint32_t h_lo = (uint32_t)(((r << 32) + R - 1) / R), h_hi = (uint32_t)((((r + 1) << 32) + R - 1) / R - 1);
-        const uint64_t s_lo = __umulhi(h_lo, (uint32_t)src.n_regions), s_hi = __umulhi(h_hi, (uint32_t)src.n_regions);
-        for (uint64_t sr = s_lo; sr <= s_hi; ++sr) {
+        uint64_t s_lo = __umulhi(h_lo, (uint32_t)src.n_regions), s_hi = __umulhi(h_hi, (uint32_t)src.n_regions);
+        if (s_lo < src.reg_lo) s_lo = src.reg_lo;                      // a source window holds nothing outside its regions
+        if (s_hi >= src.reg_hi) s_hi = src.reg_hi - 1;                  // (reg_hi > 0; s_hi < s_lo: no iteration)
+        for (uint64_t sr = s_lo; sr <= s_hi && src.reg_hi > src.reg_lo; ++sr) {
             const ulonglong2* sslots = reinterpret_cast<const ulonglong2*>(src.slots + (sr << REGION_SHIFT));
             // the whole source region in flight at once (one 16-byte load per slot, unconditional)
             ulonglong2 sv[SPT];
@@ -1280,8 +1282,9 @@ __global__ __launch_bounds__(P3_THREADS, 6) void k_merge_regions(TableView dst, 
 }
 // rehash into a bigger table (growth): exact move of physical state
 __global__ __launch_bounds__(256) void k_rehash(TableView dst, TableView old) {
-    const uint64_t n_old = old.n_regions << REGION_SHIFT;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t s0 = old.reg_lo << REGION_SHIFT, n_old = (old.reg_hi - old.reg_lo) << REGION_SHIFT;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_old; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = s0 + j;
         const Slot s = old.slots[i];
         if (s.w0 == 0) continue;
         const uint64_t h = slot_hash(old, s.w0 & REM_MASK, i >> REGION_SHIFT);
@@ -1331,9 +1334,9 @@ __global__ __launch_bounds__(256) void k_summary(TableView t, SummaryOut* out, u
     for (uint32_t i = threadIdx.x; i < HIST_SMALL; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
     uint64_t total = 0, uniq = 0, distinct = 0, edges = 0;
-    const uint64_t n = t.n_regions << REGION_SHIFT;
+    const uint64_t s0 = t.reg_lo << REGION_SHIFT, n = (t.reg_hi - t.reg_lo) << REGION_SHIFT;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const Slot* s = t.slots + i;
+        const Slot* s = t.slots + s0 + i;
         if (s->w0 == 0) continue;
         Logical L = slot_logical(t, s);
         if (L.cov == 0) continue;                 // cannot happen (a key is inserted with cov >= 1)
@@ -1368,8 +1371,8 @@ __global__ __launch_bounds__(256) void k_export(TableView t, uint32_t map_count,
     __shared__ uint32_t s_wave[4];
     __shared__ unsigned long long s_base;
     const int tid = threadIdx.x;
-    const uint64_t n = t.n_regions << REGION_SHIFT;                    // a multiple of 1024
-    for (uint64_t tile = blockIdx.x; tile < n / 1024; tile += gridDim.x) {
+    const uint64_t tile0 = (t.reg_lo << REGION_SHIFT) / 1024, tile1 = (t.reg_hi << REGION_SHIFT) / 1024;      // whole regions: multiples of 1024 slots
+    for (uint64_t tile = tile0 + blockIdx.x; tile < tile1; tile += gridDim.x) {
         uint64_t w0[4], e8[4], key[4];
         uint32_t take = 0;
 #pragma unroll
@@ -1452,6 +1455,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_lookup(TableView t, const uint
             b.fw = b.bw = b.cov = 0; b.isFw = 0; b.pad[0] = b.pad[1] = b.pad[2] = 0;
             Logical L;
             const uint64_t h = table_hash(key, (uint32_t)k);
+            if (!table_owns(t, h)) return;                                  // a window evaluates the k-mers of its own buckets (like :150 for map ranges)
             const Slot* s = table_find(t, h);                              // :153
             if (s) {
                 L = logical_of(t, h, s->w0, s->e8);                        // :156-166 (8-bit or 32-bit tier)

@@ -46,7 +46,11 @@ struct kq_handle {
     hipStream_t own_stream = nullptr, stream = nullptr;
     int n_cu = 256;
     Slot* slots = nullptr;
-    uint64_t n_regions = 0;
+    uint64_t n_regions = 0;          // of the table's geometry (the scale of the hash -> region map)
+    // window (multi-GPU shards, KQ_OPT_BUCKET_WINDOW): only the regions of the hash-prefix buckets [win_lo, win_hi) are
+    // allocated; `slots` is the allocation, view().slots the address region 0 would have
+    uint32_t win_lo = 0, win_hi = 256;
+    bool windowed = false;
     HcSlot* hc = nullptr;
     uint64_t hc_cap = 0;
     uint32_t* rstart = nullptr;      // device: first top-32 hash value of every region (n_regions + 1 entries)
@@ -90,12 +94,16 @@ struct kq_handle {
     void* hot = nullptr; size_t hot_bytes = 0;         // k_count_regions' list of skewed regions
 
     TableView view() const {
-        TableView v; v.slots = slots; v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; v.k = (uint32_t)k;
+        TableView v; v.slots = slots - (reg_lo() << REGION_SHIFT); v.n_regions = n_regions; v.hc = hc; v.hc_mask = hc_cap - 1; v.st = st; v.k = (uint32_t)k;
+        v.reg_lo = reg_lo(); v.reg_hi = reg_hi();
         v.rps = k >= HI_K ? (uint32_t)(n_regions >> 8) : 0u;
         v.rstart = rstart;
         return v;
     }
-    uint64_t n_slots() const { return n_regions << REGION_SHIFT; }
+    uint64_t reg_lo() const { return windowed ? (uint64_t)win_lo * (n_regions >> 8) : 0; }
+    uint64_t reg_hi() const { return windowed ? (uint64_t)win_hi * (n_regions >> 8) : n_regions; }
+    uint64_t n_alloc_regions() const { return reg_hi() - reg_lo(); }
+    uint64_t n_slots() const { return n_alloc_regions() << REGION_SHIFT; }      // allocated slots
 };
 
 static void marks_reset(kq_handle* h);
@@ -132,13 +140,14 @@ static void materialize(kq_handle* h) {
     clear_main(h, h->slots, h->n_slots());
     h->slots_dirty = false;
 }
-static int alloc_main(kq_handle* h, uint64_t n_regions, Slot** out, uint32_t** rstart_out) {
+// `alloc_regions` of the n_regions of the geometry get memory (all of them unless the table is a window)
+static int alloc_main(kq_handle* h, uint64_t n_regions, uint64_t alloc_regions, Slot** out, uint32_t** rstart_out) {
     Slot* p = nullptr;
     uint32_t* rs = nullptr;
-    size_t bytes = (size_t)(n_regions << REGION_SHIFT) * sizeof(Slot);
+    size_t bytes = (size_t)(alloc_regions << REGION_SHIFT) * sizeof(Slot);
     HIPC(hipMalloc((void**)&p, bytes));
     if (hipMalloc((void**)&rs, (size_t)(n_regions + 1) * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(p); return fail(KQ_ERR_NOMEM, "region index allocation failed"); }
-    clear_main(h, p, n_regions << REGION_SHIFT);
+    clear_main(h, p, alloc_regions << REGION_SHIFT);
     hipLaunchKernelGGL(k_region_starts, dim3(grid_for(h, n_regions + 1, 256)), dim3(256), 0, h->stream, rs, n_regions);
     *out = p; *rstart_out = rs;
     return KQ_OK;
@@ -177,12 +186,12 @@ static int check_errors(kq_handle* h) {
 static int grow_main(kq_handle* h, uint64_t need_slots) {
     int frc = flush_pending(h);          // pending records are sorted by the regions of the current geometry
     if (frc) return frc;
-    uint64_t want = h->n_slots();
-    while (want < need_slots) want *= 2;
-    const uint64_t new_regions = want >> REGION_SHIFT;
+    uint64_t want = h->n_slots(), new_regions = h->n_regions;       // doubling keeps every multiple the geometry (and a window) needs
+    while (want < need_slots) { want *= 2; new_regions *= 2; }
+    if (new_regions >= (1ull << 32)) return fail(KQ_ERR_TABLE_FULL, "cannot grow k-mer table to %llu slots: region index overflow", (unsigned long long)want);
     Slot* fresh = nullptr;
     uint32_t* fresh_rs = nullptr;
-    int rc = alloc_main(h, new_regions, &fresh, &fresh_rs);
+    int rc = alloc_main(h, new_regions, want >> REGION_SHIFT, &fresh, &fresh_rs);
     if (rc) return rc == KQ_ERR_NOMEM ? fail(KQ_ERR_TABLE_FULL, "cannot grow k-mer table to %llu slots: out of device memory",
                                              (unsigned long long)want) : rc;
     Slot* old = h->slots; const uint64_t n_old = h->n_slots();
@@ -313,6 +322,43 @@ int kq_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
     return KQ_OK;
 }
 
+// table geometry: region counts the record formats can address
+static uint64_t round_regions(uint64_t regions, int k) {
+    if (regions < 16) regions = 16;
+    // FMT_NARROW / FMT_TOP8 records: 256 hash-prefix buckets of whole regions; k >= HI_K needs it for every table
+    // (a slot drops the top 8 hash bits, which its region then implies)
+    if (regions >= (uint64_t)NB_MAX || k >= HI_K) regions = (regions + 255) / 256 * 256;
+    if (regions >= (1ull << 19)) {                                                  // ... of 2^s sub-buckets of whole regions each, <= 256 regions per sub-bucket
+        uint32_t sbits = 3;
+        while (sbits < SUB_BITS_MAX && (((regions + 255) / 256) >> sbits) > 256) ++sbits;
+        const uint64_t unit = 256ull << sbits;
+        regions = (regions + unit - 1) / unit * unit;
+    }
+    return regions;
+}
+// KQ_OPT_BUCKET_WINDOW: the (empty) table becomes the window [lo, hi) of the 256 hash-prefix buckets of a geometry that is
+// 256 / (hi - lo) times larger: the memory stays what kq_create sized, the handle then holds -- and answers for -- only
+// the k-mers of those buckets (a multi-GPU shard; kq_insert_sharded_dev brings them)
+static int set_window(kq_handle* h, uint32_t lo, uint32_t hi) {
+    if (lo >= hi || hi > 256) return fail(KQ_ERR_INVALID, "bucket window [%u, %u) is not a range of the 256 hash-prefix buckets", lo, hi);
+    if (h->k > (int)NARROW_MAX_K) return fail(KQ_ERR_INVALID, "bucket windows need k <= %u (5-byte records)", NARROW_MAX_K);
+    if (!h->table_empty || h->n_pend || h->kmers_bound) return fail(KQ_ERR_INVALID, "the bucket window is chosen before anything is counted");
+    const uint64_t nb = hi - lo;
+    const uint64_t alloc_now = h->n_alloc_regions();
+    uint64_t virt = round_regions(std::max<uint64_t>((alloc_now + nb - 1) / nb * 256, (uint64_t)NB_MAX), h->k);
+    if (virt >= (1ull << 32)) return fail(KQ_ERR_INVALID, "bucket window too narrow for a table of %llu regions", (unsigned long long)alloc_now);
+    HIPC(hipStreamSynchronize(h->stream));
+    if (h->slots) HIPC(hipFree(h->slots));
+    if (h->rstart) HIPC(hipFree(h->rstart));
+    h->slots = nullptr; h->rstart = nullptr;
+    h->n_regions = virt; h->win_lo = lo; h->win_hi = hi; h->windowed = !(lo == 0 && hi == 256);
+    int rc = alloc_main(h, virt, h->n_alloc_regions(), &h->slots, &h->rstart);
+    if (rc) return rc;
+    h->slots_dirty = false;
+    HIPC(hipStreamSynchronize(h->stream));
+    return KQ_OK;
+}
+
 int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capacity_hint) {
     if (!out) return fail(KQ_ERR_INVALID, "out is null");
     *out = nullptr;
@@ -340,18 +386,8 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
         }
         (void)hipMemsetAsync(h->st, 0, sizeof(DevState), h->stream);
         uint64_t slots = (uint64_t)((double)(capacity_hint ? capacity_hint : (1u << 20)) / 0.7);   // load <= 0.7 at the hinted size
-        uint64_t regions = (slots + REGION_SLOTS - 1) >> REGION_SHIFT;
-        if (regions < 16) regions = 16;
-        // FMT_NARROW / FMT_TOP8 records: 256 hash-prefix buckets of whole regions; k >= HI_K needs it for every table
-        // (a slot drops the top 8 hash bits, which its region then implies)
-        if (regions >= (uint64_t)NB_MAX || k >= HI_K) regions = (regions + 255) / 256 * 256;
-        if (regions >= (1ull << 19)) {                                                  // ... of 2^s sub-buckets of whole regions each, <= 256 regions per sub-bucket
-            uint32_t sbits = 3;
-            while (sbits < SUB_BITS_MAX && (((regions + 255) / 256) >> sbits) > 256) ++sbits;
-            const uint64_t unit = 256ull << sbits;
-            regions = (regions + unit - 1) / unit * unit;
-        }
-        rc = alloc_main(h, regions, &h->slots, &h->rstart); if (rc) break;
+        const uint64_t regions = round_regions((slots + REGION_SLOTS - 1) >> REGION_SHIFT, k);
+        rc = alloc_main(h, regions, regions, &h->slots, &h->rstart); if (rc) break;
         h->n_regions = regions;
         uint64_t hc = 1u << 16;
         rc = alloc_hc(h, hc, &h->hc); if (rc) break;
@@ -436,6 +472,9 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             if (h->arena && value != h->pend_budget) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
             h->pend_budget = value; return KQ_OK;
         }
+        case KQ_OPT_BUCKET_WINDOW:
+            HIPC(hipSetDevice(h->device));
+            return set_window(h, (uint32_t)(value & 0xFFFF), (uint32_t)((value >> 16) & 0xFFFF));
         case KQ_OPT_SLICE_KMERS:
             if (value < 1) return fail(KQ_ERR_INVALID, "KQ_OPT_SLICE_KMERS must be positive");
             h->slice_kmers = (uint64_t)value; h->slice_user = true; return KQ_OK;
@@ -789,7 +828,7 @@ static int flush_pending(kq_handle* h) {
     }
     unsigned long long* hot = (unsigned long long*)h->hot;       // [0] = count, then up to R region ids
     HIPC(hipMemsetAsync(hot, 0, 8, h->stream));
-    const dim3 grid((unsigned)std::min<uint64_t>(R, 1u << 30)), grid_hot(h->n_cu), block(P3_THREADS);   // one workgroup per region: dispatcher-balanced
+    const dim3 grid((unsigned)std::min<uint64_t>(h->n_alloc_regions(), 1u << 30)), grid_hot(h->n_cu), block(P3_THREADS);   // one workgroup per (allocated) region: dispatcher-balanced
     // 1: the slot array holds the empty image (skip reading it); 2: logically empty but not initialised (lazy kq_clear):
     // also write the image of regions without records.  A dirty array is never read, whatever table_empty says
     const int empty = h->slots_dirty ? 2 : h->table_empty ? 1 : 0;
@@ -1194,9 +1233,18 @@ __global__ void k_sharded_segments(const unsigned long long* __restrict__ start 
     seg_hi[b * n_peers + q] = start[j] + counts[j];
 }
 
+// first bucket of part p of n_parts: the parts are contiguous ranges of the 256 hash-prefix buckets (kreeq_amd/dist.py: bucket_range)
+static inline uint32_t part_first_bucket(int p, int n_parts) { return (uint32_t)(((uint64_t)p * 256 + n_parts - 1) / n_parts); }
+__global__ void k_bucket_meta(const unsigned long long* __restrict__ seg_off, uint32_t n_parts, unsigned long long* __restrict__ counts) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_parts << NARROW_CBITS) return;
+    const uint32_t p = j >> NARROW_CBITS, b = j & ((1u << NARROW_CBITS) - 1u);
+    const uint32_t lo = (uint32_t)(((uint64_t)p * 256 + n_parts - 1) / n_parts), hi = (uint32_t)(((uint64_t)(p + 1) * 256 + n_parts - 1) / n_parts);
+    counts[j] = (b >= lo && b < hi) ? seg_off[b + 1] - seg_off[b] : 0ull;
+}
 int kq_emit_sharded_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts, uint32_t* d_recs, uint8_t* d_aux, uint64_t cap,
                         uint64_t* d_bucket_counts, uint64_t* part_counts) {
-    if (!h || !part_counts || !d_bucket_counts || n_parts < 1 || n_parts > h->map_count || n_parts > 256 || (!d_bases && len))
+    if (!h || !part_counts || !d_bucket_counts || n_parts < 1 || n_parts > 256 || (!d_bases && len))
         return fail(KQ_ERR_INVALID, "bad argument");
     if (h->k > (int)NARROW_MAX_K) return fail(KQ_ERR_INVALID, "5-byte records need k <= %u (use kq_emit_packed_dev)", NARROW_MAX_K);
     HIPC(hipSetDevice(h->device));
@@ -1204,25 +1252,24 @@ int kq_emit_sharded_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_p
     const uint64_t n_groups = (uint64_t)n_parts << NARROW_CBITS;
     HIPC(hipMemsetAsync(d_bucket_counts, 0, n_groups * 8, h->stream));
     if (len < (uint64_t)h->k) { HIPC(hipStreamSynchronize(h->stream)); return KQ_OK; }
-    if (len - h->k + 1 >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "an owner split handles fewer than 2^32 k-mer starts per call (got %llu): cut the batch", (unsigned long long)(len - h->k + 1));
+    if (len - h->k + 1 >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "a bucket split handles fewer than 2^32 k-mer starts per call (got %llu): cut the batch", (unsigned long long)(len - h->k + 1));
     if (cap < len - h->k + 1 || !d_recs || !d_aux) return fail(KQ_ERR_CAPACITY, "record buffers too small: need room for %llu records", (unsigned long long)(len - h->k + 1));
     const uint8_t* ab; uint64_t lead;
     aligned_view(d_bases, &ab, &lead);
     PartPlan p;
     int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), 1u << NARROW_CBITS, true, n_groups);
     if (rc) return rc;
-    PartCfg cfg = p.cfg;                                          // bucket = top 8 hash bits, whatever this rank's table looks like
+    // the bucket split of the single-GPU count IS the owner split: bucket = top 8 hash bits, whatever this rank's table
+    // looks like, and every part is a range of buckets -- P1 writes straight into the send buffers
+    PartCfg cfg = p.cfg;
     cfg.mode = 0; cfg.narrow = 1; cfg.n_coarse = 1u << NARROW_CBITS; cfg.sub_bits = 0; if (cfg.g_shift == 0) cfg.g_shift = 1;
-    run_p1(h, &p, cfg, ab, lead, len, EmitRange{0, ~0ull}, p.recs1, p.aux1, AUX_IDX6);
-    LevelCfg lv = level_narrow(cfg);
-    lv.n_seg = 1u << NARROW_CBITS; lv.nb = (uint32_t)n_parts; lv.own_parts = (uint32_t)n_parts; lv.k = (uint32_t)h->k;
-    lv.map_count = (uint32_t)h->map_count; lv.map_mask = (h->map_count & (h->map_count - 1)) == 0 ? (uint32_t)h->map_count - 1 : 0;
-    run_level(h, &p, lv, p.recs1, p.aux1, (uint64_t*)d_recs, d_aux);
-    hipLaunchKernelGGL(k_group_counts, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, h->stream, p.group_base, n_groups, (unsigned long long*)d_bucket_counts);
-    std::vector<unsigned long long> off((size_t)n_groups + 1);
-    HIPC(hipMemcpyAsync(off.data(), p.group_base, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    cfg.filt_lo = 0; cfg.filt_hi = cfg.map_count;
+    run_p1(h, &p, cfg, ab, lead, len, EmitRange{0, ~0ull}, (uint64_t*)d_recs, d_aux, AUX_IDX6);
+    hipLaunchKernelGGL(k_bucket_meta, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, h->stream, p.seg_off, (uint32_t)n_parts, (unsigned long long*)d_bucket_counts);
+    std::vector<unsigned long long> off((size_t)(1u << NARROW_CBITS) + 1);
+    HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n_parts; ++i) part_counts[i] = off[((size_t)i + 1) << NARROW_CBITS] - off[(size_t)i << NARROW_CBITS];
+    for (int i = 0; i < n_parts; ++i) part_counts[i] = off[part_first_bucket(i + 1, n_parts)] - off[part_first_bucket(i, n_parts)];
     return KQ_OK;
 }
 
@@ -1541,7 +1588,7 @@ int kq_merge(kq_handle* dst, kq_handle* src) {
     // enough source entries to pay for streaming dst once: merge region by region in LDS; else per-entry atomics
     if (dst->merge_path == 2 || (dst->merge_path == 0 && src->st_host->slots_used * 64 >= dst->n_slots())) {
         const int empty = (dst->table_empty || dst->slots_dirty) ? 1 : 0;     // a dirty (lazily cleared) array is never read
-        hipLaunchKernelGGL(k_merge_regions, dim3((unsigned)std::min<uint64_t>(dst->n_regions, 1u << 30)), dim3(P3_THREADS), 0, dst->stream,
+        hipLaunchKernelGGL(k_merge_regions, dim3((unsigned)std::min<uint64_t>(dst->n_alloc_regions(), 1u << 30)), dim3(P3_THREADS), 0, dst->stream,
                            dst->view(), src->view(), empty);
         dst->slots_dirty = false;                       // every region image has been written
         dst->table_empty = false;

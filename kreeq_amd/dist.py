@@ -1,13 +1,21 @@
 """Bucket-sharded multi-GPU counting: one process per GPU, torch.distributed (backend "nccl" is RCCL
 on ROCm) over xGMI.
 
-Sharding = the reference's own bucket function: rank r owns maps
-[r*map_count/world, (r+1)*map_count/world) of key % map_count (src/graph-builder.cpp:95,
-src/kreeq.cpp:146).  Per read batch every rank runs K1 on ITS reads, grouping the (key, edge)
-records by owner rank; one all-to-all(v) routes them (8 B keys + 1 B edges, SoA); every rank then
-inserts what it received into its own table.  Validation: every rank scans the assembly against its
-own map range (the reference's range filter, src/kreeq.cpp:150) and the three QV counters are
-all-reduced (sum).  Summary numbers are all-reduced the same way.
+Two ownership rules, one per record format:
+
+* k <= 21 on tables of >= 2048 regions (the default k at any real size) -- HASH-PREFIX BUCKETS: rank r owns the buckets
+  [ceil(256 r / world), ceil(256 (r+1) / world)) of the top 8 bits of the table hash, and its table is the window of
+  those buckets (KQ_OPT_BUCKET_WINDOW).  The first split of the single-GPU count path (256 buckets) is then the owner
+  split as well: a rank scans its reads once, its bucket-sorted 5-byte records are already grouped by destination, one
+  all-to-all(v) routes them, and the receiver's split levels take the (bucket, peer) runs as their input segments -- the
+  N > 1 path runs the kernels of the single-GPU path and nothing more.  Validation: every rank evaluates the assembly
+  k-mers of its buckets; database files: the entries are routed to the rank that writes their map (export_db).
+* otherwise -- the reference's own bucket function: rank r owns maps [r*map_count/world, (r+1)*map_count/world) of
+  key % map_count (src/graph-builder.cpp:95, src/kreeq.cpp:146), records are grouped by owner in a split level of their
+  own (8-byte packed records up to k = 28, key + edge byte above); validation by map range (src/kreeq.cpp:150).
+
+Per read batch every rank emits records from ITS reads, one all-to-all(v) per array routes them, every rank inserts what
+it received into its own table.  QV counters, summary numbers and the coverage histogram are all-reduced (sum).
 
 The compute engine is injected (`engine`): the product uses GpuEngine (C ABI, HBM-resident
 tensors); the gloo/CPU tests drive the same routing code with a host engine of their own.
@@ -29,6 +37,31 @@ def owner_range(rank, world, map_count):
 def owner_of(keys, world, map_count):
     m = keys % np.uint64(map_count)
     return (m * np.uint64(world) // np.uint64(map_count)).astype(np.int64)
+
+
+def bucket_range(rank, world):
+    """hash-prefix buckets owned by `rank` -- must match part_first_bucket() in csrc/kreeq_amd.hip"""
+    return -(-rank * 256 // world), -(-(rank + 1) * 256 // world)
+
+
+_MIX_MUL = 0x9E3779B97F4A7C15
+
+
+def table_hash(keys, k):
+    """the library's table hash of canonical keys (kq_device.h: an invertible xorshift-multiply-xorshift on the 2k key bits,
+    left-aligned in 64 bits), vectorised; used by tests and by the host engine of the gloo tests"""
+    keys = np.asarray(keys, dtype=np.uint64)
+    pad = np.uint64(64 - 2 * k)
+    x = keys ^ (keys >> np.uint64(k))
+    with np.errstate(over="ignore"):
+        x = (x * np.uint64(_MIX_MUL)) << pad
+    hi_mask = np.uint64((~0 << (64 - 2 * k)) & 0xFFFFFFFFFFFFFFFF)
+    return x ^ ((x >> np.uint64(k)) & hi_mask)
+
+
+def bucket_of(keys, k):
+    """hash-prefix bucket (top 8 bits of the table hash) of canonical keys"""
+    return (table_hash(keys, k) >> np.uint64(56)).astype(np.int64)
 
 
 class GpuEngine:
@@ -77,6 +110,10 @@ class GpuEngine:
         counts = self.db.emit_partitioned_dev(bases.data_ptr(), n, n_parts, keys.data_ptr(), edges.data_ptr(), keys.numel())
         tot = int(counts.sum())
         return [keys[:tot], edges[:tot]], counts.astype(np.int64)
+
+    def set_window(self, bucket_lo, bucket_hi):
+        """this rank's table holds the hash-prefix buckets [bucket_lo, bucket_hi) only (KQ_OPT_BUCKET_WINDOW)"""
+        self.db.set_option("bucket_window", bucket_lo | (bucket_hi << 16))
 
     def count(self, bases: torch.Tensor):
         """fused K1+K2 (no record materialisation): the single-GPU path"""
@@ -131,9 +168,14 @@ class ShardedCounter:
         self.map_lo, self.map_hi = owner_range(self.rank, self.world, map_count)
         # every rank must emit the record format every rank can insert: 5-byte records only if all tables allow them
         if self.world > 1 and hasattr(engine, "sharded5"):
-            flag = torch.tensor([1 if engine.sharded5 else 0], dtype=torch.int64, device=engine.device)
+            flag = torch.tensor([1 if engine.sharded5 else 0], dtype=torch.int64, device=getattr(engine, "device", torch.device("cpu")))
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             engine.sharded5 = bool(flag.item())
+        # ownership by hash-prefix bucket range (module docstring): this rank's table becomes the window of its buckets
+        self.bucket_mode = bool(getattr(engine, "sharded5", False))
+        self.bucket_lo, self.bucket_hi = bucket_range(self.rank, self.world)
+        if self.bucket_mode and self.world > 1:
+            engine.set_window(self.bucket_lo, self.bucket_hi)
 
     def _stream_ctx(self):
         import contextlib
@@ -246,7 +288,10 @@ class ShardedCounter:
     def validate(self, bases: torch.Tensor, cov_cutoff=0):
         """every rank passes the SAME assembly sequence; returns the global (missing, total, edgeMissing)"""
         with self._stream_ctx():
-            ctr = self.engine.lookup(bases, self.map_lo, self.map_hi, cov_cutoff)
+            if self.bucket_mode:          # the window answers for the k-mers of its buckets only
+                ctr = self.engine.lookup(bases, 0, self.map_count, cov_cutoff)
+            else:
+                ctr = self.engine.lookup(bases, self.map_lo, self.map_hi, cov_cutoff)
             if self.world > 1:
                 dist.all_reduce(ctr, op=dist.ReduceOp.SUM, group=self.group)
             return ctr.cpu().numpy().astype(np.uint64)
@@ -284,7 +329,10 @@ class ShardedCounter:
         All ranks must see the same directory (one node)."""
         from . import hostdb
 
-        ent = self.engine.export(self.map_lo, self.map_hi)
+        if self.bucket_mode and self.world > 1:
+            ent = self._route_entries_to_map_owners()
+        else:
+            ent = self.engine.export(self.map_lo, self.map_hi)
         hc = hostdb.write_maps(db_dir, self.map_count, self.map_lo, self.map_hi, ent)
         if self.world > 1:
             gathered = [None] * self.world if self.rank == 0 else None
@@ -296,6 +344,23 @@ class ShardedCounter:
         if self.world > 1:
             dist.barrier(group=self.group)
         return len(ent)
+
+    def _route_entries_to_map_owners(self):
+        """bucket ownership: a shard holds k-mers of every map.  Every rank exports, per destination, the entries of the
+        maps that destination writes; one all-to-all(v) of the raw entries (48 B each) brings every map to its writer."""
+        from .capi import ENTRY_DTYPE
+
+        parts = [np.ascontiguousarray(self.engine.export(*owner_range(d, self.world, self.map_count)), dtype=ENTRY_DTYPE) for d in range(self.world)]
+        dev = getattr(self.engine, "device", torch.device("cpu"))
+        send_counts = torch.tensor([p.nbytes for p in parts], dtype=torch.int64, device=dev)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        rc = recv_counts.cpu().tolist()
+        raw = np.concatenate([p.view(np.uint8).reshape(-1) for p in parts]) if parts else np.zeros(0, np.uint8)
+        send = torch.from_numpy(raw).to(dev)
+        recv = torch.empty(int(sum(rc)), dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=[p.nbytes for p in parts], group=self.group)
+        return np.frombuffer(recv.cpu().numpy().tobytes(), dtype=ENTRY_DTYPE)
 
     def summary(self):
         with self._stream_ctx():

@@ -810,20 +810,26 @@ def test_lookup_keys_and_branch_scan(kq, O):
 
 
 @pytest.mark.parametrize("k,hint,n_parts,n_peers", [(21, 5_000_000, 3, 2), (21, 40_000_000, 8, 3), (17, 5_000_000, 2, 1), (21, 5_870_000, 5, 4),
-                                                    (21, 100_000_000, 2, 3)])      # >= 2^16 regions per receiver: FMT_TIGHT pending sets
+                                                    (21, 100_000_000, 2, 3),      # >= 2^16 regions per receiver: FMT_TIGHT pending sets
+                                                    (21, 5_000_000, 1, 2)])       # one part: an ordinary (unwindowed) table
 def test_sharded5_emit_exchange_insert(kq, O, k, hint, n_parts, n_peers):
-    """multi-GPU exchange with 5-byte records, emulated in one process: n_peers senders split their reads by owner part
-    (kq_emit_sharded_dev), each of n_parts receivers gets its run from every peer plus the per-bucket counts and inserts
-    them (kq_insert_sharded_dev) -- every receiver must end up with exactly the oracle's k-mers of the maps it owns"""
+    """multi-GPU exchange with 5-byte records, emulated in one process: n_peers senders split their reads by hash-prefix
+    bucket (kq_emit_sharded_dev: the parts are bucket ranges), each of n_parts receivers -- a table that is the WINDOW of
+    its buckets (KQ_OPT_BUCKET_WINDOW) -- gets its run from every peer plus the per-bucket counts and inserts them
+    (kq_insert_sharded_dev).  Every receiver must end up with exactly the oracle's k-mers of its buckets, and the QV
+    counters of the shards must add up to the oracle's."""
     import torch
 
-    from kreeq_amd.dist import owner_range
+    from kreeq_amd.dist import bucket_of, bucket_range
 
     batches = [H.synth_reads(9000 + 700 * q, 150, 300_000, seed=500 + q, err=0.01, n_rate=0.002)[0] for q in range(n_peers)]
+    _, genome = H.synth_reads(10, 150, 300_000, seed=500)
     cpu = O.OracleDB(k, 128)
     for b in batches:
         cpu.count_batch(b, threads=8)
+        cpu.count_batch(b, threads=8)             # the receivers insert every run twice
     want = cpu.export()
+    want_bucket = bucket_of(want["key"], k)
     dev = torch.device("cuda", 0)
     sender = kq.KreeqDB(k, 128)                   # a sender needs no particular table
     runs, metas = [], []
@@ -834,26 +840,91 @@ def test_sharded5_emit_exchange_insert(kq, O, k, hint, n_parts, n_peers):
         meta = torch.empty((n_parts, 256), dtype=torch.int64, device=dev)
         counts = sender.emit_sharded_dev(t.data_ptr(), t.numel(), n_parts, recs.data_ptr(), aux.data_ptr(), recs.numel(), meta.data_ptr())
         assert meta.sum(dim=1).cpu().tolist() == counts.tolist()
+        for p in range(n_parts):                  # a part's counts lie in its bucket range only
+            lo, hi = bucket_range(p, n_parts)
+            assert int(meta[p, :lo].sum()) == 0 and int(meta[p, hi:].sum()) == 0
         off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         runs.append([(recs[off[p]:off[p + 1]].clone(), aux[off[p]:off[p + 1]].clone()) for p in range(n_parts)])
         metas.append(meta.clone())
     total = 0
+    ctr_direct, ctr_part = np.zeros(3, dtype=np.uint64), np.zeros(3, dtype=np.uint64)
+    summ = {"total": 0, "unique": 0, "distinct": 0, "edges": 0}
     for p in range(n_parts):
         recv = kq.KreeqDB(k, 128, capacity_hint=hint)
         recv.set_option("trust_capacity", 1)
+        lo, hi = bucket_range(p, n_parts)
+        if n_parts > 1:
+            before = recv.info()["slots_total"]
+            recv.set_option("bucket_window", lo | (hi << 16))
+            assert before <= recv.info()["slots_total"] <= 2 * before + (1 << 22)      # the window keeps the memory kq_create sized (rounded up)
         r = torch.cat([runs[q][p][0] for q in range(n_peers)])
         a = torch.cat([runs[q][p][1] for q in range(n_peers)])
         m = torch.stack([metas[q][p] for q in range(n_peers)]).contiguous()
         recv.insert_sharded_dev(r.data_ptr(), a.data_ptr(), r.numel(), n_peers, m.data_ptr())
-        # a second, pending-set round on the filled table: the same records again double every count
+        # a second, pending-set round on the filled table
         recv.insert_sharded_dev(r.data_ptr(), a.data_ptr(), r.numel(), n_peers, m.data_ptr())
         got = recv.export()
-        lo, hi = owner_range(p, n_parts, 128)
-        mine = want[(want["key"] % np.uint64(128) >= lo) & (want["key"] % np.uint64(128) < hi)]
-        assert len(got) == len(mine) and np.array_equal(got["key"], mine["key"])
-        assert np.array_equal(got["cov"], 2 * mine["cov"]) and np.array_equal(got["fw"], 2 * mine["fw"]) and np.array_equal(got["bw"], 2 * mine["bw"])
+        mine = want[(want_bucket >= lo) & (want_bucket < hi)]
+        assert H.entries_equal(got, mine)
         total += len(got)
+        s = recv.summary()
+        for f in summ:
+            summ[f] += s[f]
+        # the shard answers for its buckets only: direct probes and the region-wise path
+        recv.set_option("lookup_path", "direct")
+        ctr_direct += recv.lookup_sequence(genome)[0]
+        recv.set_option("lookup_path", "partitioned")
+        ctr_part += recv.lookup_sequence(genome)[0]
+        # map-range export of a shard (what the database writer of the multi-GPU driver asks for)
+        sub = recv.export(32, 96)
+        mm = mine["key"] % np.uint64(128)
+        assert H.entries_equal(sub, mine[(mm >= 32) & (mm < 96)])
     assert total == len(want)
+    c_cpu, _ = cpu.validate_sequence(genome)
+    assert np.array_equal(ctr_direct, c_cpu) and np.array_equal(ctr_part, c_cpu)
+    ref = cpu.summary()
+    assert all(summ[f] == ref[f] for f in summ)
+
+
+def test_bucket_window_rules(kq, O):
+    """KQ_OPT_BUCKET_WINDOW: only on an empty handle with k <= 21; a windowed handle drops foreign k-mers on every count path"""
+    from kreeq_amd.dist import bucket_of
+
+    k = 21
+    b, _ = H.synth_reads(9000, 150, 200_000, seed=41, err=0.01, n_rate=0.002)
+    db = kq.KreeqDB(31, 128, capacity_hint=5_000_000)
+    with pytest.raises(kq.KqError):
+        db.set_option("bucket_window", 0 | (128 << 16))          # k > 21
+    db = kq.KreeqDB(k, 128, capacity_hint=5_000_000)
+    with pytest.raises(kq.KqError):
+        db.set_option("bucket_window", 7 | (7 << 16))            # empty range
+    db.count_batch(b)
+    with pytest.raises(kq.KqError):
+        db.set_option("bucket_window", 0 | (128 << 16))          # not empty any more
+    cpu = O.OracleDB(k, 128)
+    cpu.count_batch(b, threads=8)
+    want = cpu.export()
+    wb = bucket_of(want["key"], k)
+    for path in ("direct", "partitioned"):
+        win = kq.KreeqDB(k, 128, capacity_hint=5_000_000)
+        win.set_option("bucket_window", 100 | (171 << 16))
+        win.set_option("count_path", path)
+        win.count_batch(b)
+        assert H.entries_equal(win.export(), want[(wb >= 100) & (wb < 171)])
+        # growth keeps the window (no trust_capacity: the worst-case reservation of the later batches forces a rehash)
+        small = kq.KreeqDB(k, 128, capacity_hint=1_000_000)
+        small.set_option("bucket_window", 100 | (171 << 16))
+        small.set_option("count_path", path)
+        slots0 = small.info()["slots_total"]
+        cpu2 = O.OracleDB(k, 128)
+        for i in range(3):
+            bi, _ = H.synth_reads(9000, 150, 2_000_000, seed=60 + i, err=0.01)
+            small.count_batch(bi)
+            cpu2.count_batch(bi, threads=8)
+        w2 = cpu2.export()
+        w2b = bucket_of(w2["key"], k)
+        assert H.entries_equal(small.export(), w2[(w2b >= 100) & (w2b < 171)])
+        assert small.info()["slots_total"] > slots0
 
 
 def test_pipelined_host_ingest(kq, O):
