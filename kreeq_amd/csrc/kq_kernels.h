@@ -258,12 +258,8 @@ __device__ __forceinline__ uint32_t seg_of_unit(const unsigned long long* unit_b
     return lo;
 }
 // pass A: per-unit bin counts -> M2[unit][bin] (u32)
-// bin of a narrow record in an owner split (LevelCfg::own_parts): the k-mer is recovered from its hash bits
-__device__ __forceinline__ uint32_t owner_bin(const LevelCfg& lv, uint32_t bucket, uint32_t main32, uint32_t aux) {
-    return owner_part_of(key_of_hash(narrow_hash(bucket, main32, aux), lv.k), lv.map_count, lv.map_mask, lv.own_parts);
-}
 template <int FMT>
-__global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
+__global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restrict__ recs, const uint8_t* __restrict__ /*recs_aux: no bin function reads it*/, LevelCfg lv,
                                                         const unsigned long long* __restrict__ seg_off, const unsigned long long* __restrict__ seg_hi,
                                                         const unsigned long long* __restrict__ unit_base, uint32_t* __restrict__ m2) {
     __shared__ uint32_t s_hist[NB_MAX];
@@ -278,26 +274,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_lv_hist(const uint64_t* __restri
         // 8 records per lane in flight, loaded unconditionally (index clamped): a load inside a branch per
         // iteration costs a full memory latency per record (s_waitcnt vmcnt(0) right behind it)
         const uint64_t last = hi - 1;                                   // a unit is never empty
-        if (FMT == FMT_NARROW && lv.own_parts) {                         // owner split: the bin needs the whole hash (u32 + the byte's low bits)
-            // few bins: 2^rs counters per bin (by lane), folded below -- one counter per owner would serialise the atomics
-            const uint32_t* r32 = reinterpret_cast<const uint32_t*>(recs);
-            const uint32_t rs = lv.rep_shift, sub = threadIdx.x & ((1u << rs) - 1u);
-            for (uint32_t i = lv.nb + threadIdx.x; i < (lv.nb << rs); i += MS_THREADS) s_hist[i] = 0;
-            __syncthreads();
-            for (uint64_t base = lo; base < hi; base += 4ull * MS_THREADS) {
-                uint32_t r[4], a[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const uint64_t i = min(base + (uint64_t)j * MS_THREADS + threadIdx.x, last); r[j] = r32[i]; a[j] = recs_aux[i]; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (base + (uint64_t)j * MS_THREADS + threadIdx.x < hi) atomicAdd(&s_hist[(owner_bin(lv, b, r[j], a[j]) << rs) | sub], 1u);
-            }
-            __syncthreads();
-            uint32_t folded = 0;
-            if (threadIdx.x < lv.nb) for (uint32_t c = 0; c < (1u << rs); ++c) folded += s_hist[(threadIdx.x << rs) | c];
-            __syncthreads();
-            if (threadIdx.x < lv.nb) s_hist[threadIdx.x] = folded;
-        } else if (FMT == FMT_NARROW) {
+        if (FMT == FMT_NARROW) {
             // 16-byte loads of four u32 records at absolute quad indices (the array is 16-byte aligned and has
             // slack behind its last record); the quads at the unit's ends are masked per element
             const uint4* v4 = reinterpret_cast<const uint4*>(recs);
@@ -349,8 +326,8 @@ __global__ __launch_bounds__(256) void k_lv_offsets(uint32_t* __restrict__ m2, L
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_lseg = lv.n_seg / lv.spb;                       // logical segments (spb input segments each)
     if (r >= (uint64_t)n_lseg * lv.nb) return;                       // wave-uniform
-    // group r = (logical segment b, bin): segment-major, or bin-major for an owner split
-    const uint32_t b = lv.own_parts ? (uint32_t)(r % n_lseg) : (uint32_t)(r / lv.nb), bin = lv.own_parts ? (uint32_t)(r / n_lseg) : (uint32_t)(r % lv.nb);
+    // group r = (logical segment b, bin), segment-major
+    const uint32_t b = (uint32_t)(r / lv.nb), bin = (uint32_t)(r % lv.nb);
     const uint64_t u0 = unit_base[b * lv.spb], u1 = unit_base[(b + 1) * lv.spb];
     unsigned long long run = 0;
     for (uint64_t base = u0; base < u1; base += 64) {
@@ -372,7 +349,7 @@ __global__ __launch_bounds__(256) void k_lv_offsets_thread(uint32_t* __restrict_
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_lseg = lv.n_seg / lv.spb;
     if (r >= (uint64_t)n_lseg * lv.nb) return;
-    const uint32_t b = lv.own_parts ? (uint32_t)(r % n_lseg) : (uint32_t)(r / lv.nb), bin = lv.own_parts ? (uint32_t)(r / n_lseg) : (uint32_t)(r % lv.nb);
+    const uint32_t b = (uint32_t)(r / lv.nb), bin = (uint32_t)(r % lv.nb);
     const uint64_t u0 = unit_base[b * lv.spb], u1 = unit_base[(b + 1) * lv.spb];
     unsigned long long run = 0;
     for (uint64_t u = u0; u < u1; ++u) {
@@ -403,14 +380,13 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
     __shared__ uint32_t s_rst[TIGHT ? NBC : 1];     // TIGHT (last level, bin = region): rstart[] of the segment's regions
     const uint32_t nb = lv.nb;
     const uint64_t n_units = unit_base[lv.n_seg];
-    const uint32_t n_lseg = lv.n_seg / lv.spb;
     for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint32_t b_in = seg_of_unit(unit_base, lv.n_seg, u);
         const uint32_t b = lv.spb > 1 ? b_in / lv.spb : b_in;          // logical segment: bin functions and output groups
         const uint64_t lo = seg_off[b_in] + (u - unit_base[b_in]) * P2_UNIT;
         const uint64_t hi = lo + P2_UNIT < seg_hi[b_in] ? lo + P2_UNIT : seg_hi[b_in];
         for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS)
-            s.gbase[i] = (uint32_t)(group_base[lv.own_parts ? (uint64_t)i * n_lseg + b : (uint64_t)b * nb + i] + m2[u * nb + i]);
+            s.gbase[i] = (uint32_t)(group_base[(uint64_t)b * nb + i] + m2[u * nb + i]);
         if (TIGHT) {
             const uint32_t first = (b >> lv.nr_shift) * lv.nr_rps + (b & ((1u << lv.nr_shift) - 1u)) * lv.nr_sub;      // narrow_bin's origin; nr_div == 1
             for (uint32_t i = threadIdx.x; i < nb; i += LV_THREADS) s_rst[i] = lv.rstart[first + i];
@@ -447,7 +423,7 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
                     const uint32_t bn = i >= hi ? nb : narrow_bin(lv, b, (uint32_t)rec[j]);
                     rec[j] = narrow_word(tight_rec(b >> lv.nr_shift, (uint32_t)rec[j], aux[j], s_rst[bn < nb ? bn : 0u]), 0u, bn);
                 }
-                else if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : lv.own_parts ? owner_bin(lv, b, (uint32_t)rec[j], aux[j]) : narrow_bin(lv, b, (uint32_t)rec[j]));
+                else if (NARROW) rec[j] = narrow_word((uint32_t)rec[j], aux[j], i >= hi ? nb : narrow_bin(lv, b, (uint32_t)rec[j]));
                 else if (CONVERT) {
                     const uint64_t hh = rec_hash<false>(rec[j]);
                     rec[j] = narrow_word(narrow_main(hh), narrow_aux(hh, (uint32_t)(rec[j] >> REC_EDGE_SHIFT) & 63u), i >= hi ? nb : (uint32_t)(hh >> (64 - NARROW_CBITS)));

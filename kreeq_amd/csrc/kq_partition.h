@@ -65,13 +65,9 @@ struct LevelCfg {
     // narrow levels: segment b = (bucket b >> nr_shift, sub-bucket b & (2^nr_shift - 1)) starts at region
     // bucket * nr_rps + sub * nr_sub; bin = (region - that) / nr_div (nr_inv = ceil(2^32 / nr_div))
     uint32_t nr_shift, nr_rps, nr_sub, nr_div, nr_inv;
-    // multi-GPU exchange of narrow records:
-    //   spb > 1      the input has spb segments per logical segment (one run per peer rank): input segment s belongs to
-    //                logical segment s / spb, whose units and output groups they share (receive side)
-    //   own_parts    > 0: bin = owner part of the record's k-mer (key % map_count scaled to own_parts, src/graph-builder.cpp:95)
-    //                and the output is BIN-major (group = bin * n_seg + segment): one contiguous run per owner, the records
-    //                of a bucket contiguous inside it (send side)
-    uint32_t spb, own_parts, map_count, map_mask;
+    // multi-GPU exchange of narrow records (receive side): spb > 1 = the input has spb segments per logical segment (one
+    // run per peer rank): input segment s belongs to logical segment s / spb, whose units and output groups they share
+    uint32_t spb;
     uint32_t rep_shift;     // rank replication of the multisplit (block_multisplit's rs), set by the host from nb
     const uint32_t* rstart = nullptr; // non-null: this (last, narrow) level writes FMT_TIGHT records relative to rstart[region]
 };

@@ -684,7 +684,7 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
     else if (fmt == FMT_WIDE) hipLaunchKernelGGL(k_lv_hist<FMT_WIDE>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv_, p->seg_off, seg_hi, p->unit_base, p->m2);
     else hipLaunchKernelGGL(k_lv_hist<FMT_PACK8>, dim3(unit_grid), dim3(MS_THREADS), 0, h->stream, in, in_aux, lv_, p->seg_off, seg_hi, p->unit_base, p->m2);
     // few units per segment (many segments): one thread per group; else one wave per group (a segment of thousands of units)
-    if (p->n_max / P2_UNIT + 1 <= 8 * (uint64_t)(lv.n_seg / lv.spb) && !lv.own_parts)
+    if (p->n_max / P2_UNIT + 1 <= 8 * (uint64_t)(lv.n_seg / lv.spb))
         hipLaunchKernelGGL(k_lv_offsets_thread, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv_, p->unit_base, gb);
     else
         hipLaunchKernelGGL(k_lv_offsets, dim3((unsigned)((groups * 64 + 255) / 256)), dim3(256), 0, h->stream, p->m2, lv_, p->unit_base, gb);
@@ -706,7 +706,7 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
-    lv.spb = 1; lv.own_parts = 0; lv.map_count = lv.map_mask = 0;
+    lv.spb = 1;
     return lv;
 }
 // FMT_NARROW: 256 top-bit buckets -> their regions (bucket b owns regions [b * nb, (b + 1) * nb))
@@ -720,7 +720,7 @@ static LevelCfg level_narrow(const PartCfg& cfg, uint32_t sub_bits = 0, bool mid
     if (middle) { lv.n_seg = 1u << NARROW_CBITS; lv.nb = 1u << sub_bits; lv.nr_shift = 0; lv.nr_div = subsz; }
     else        { lv.n_seg = (1u << NARROW_CBITS) << sub_bits; lv.nb = subsz; lv.nr_shift = sub_bits; lv.nr_div = 1; }
     lv.nr_inv = lv.nr_div > 1 ? (uint32_t)(((1ull << 32) + lv.nr_div - 1) / lv.nr_div) : 0;
-    lv.spb = 1; lv.own_parts = 0; lv.map_count = lv.map_mask = 0;
+    lv.spb = 1;
     return lv;
 }
 // bucket -> regions for FMT_NARROW records, in one level or (large tables) two; afterwards `*sorted` holds the
@@ -737,7 +737,7 @@ static bool tight_ok(const kq_handle* h, const PartPlan& p) {
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
-    lv.spb = 1; lv.own_parts = 0; lv.map_count = lv.map_mask = 0;
+    lv.spb = 1;
     return lv;
 }
 // ---- pending sets ---------------------------------------------------------------------------------
@@ -1213,15 +1213,11 @@ int kq_emit_packed_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_pa
 }
 
 // ---- multi-GPU exchange of 5-byte records (k <= 21) -------------------------------------------------
-// Sender: P1 by hash-prefix bucket (the same 5-byte records the single-GPU count makes), then one split level by OWNER
-// inside every bucket, written owner-major: the part of every destination rank is one contiguous run whose records are
-// grouped by bucket.  Receiver: the runs of all peers are (peer, bucket) segments of its bucket -> region levels, so the
-// received records enter the ordinary narrow path without a conversion level, and 5 bytes per record cross xGMI
-// instead of 8.  kq_emit_packed_dev / kq_insert_packed_dev remain for k = 22..28 and small tables.
-__global__ void k_group_counts(const unsigned long long* __restrict__ group_base, uint64_t n_groups, unsigned long long* __restrict__ counts) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_groups) counts[i] = group_base[i + 1] - group_base[i];
-}
+// Ownership is by hash-prefix bucket range, so the sender's work is the first split of the single-GPU count and nothing
+// else: P1 writes the bucket-sorted 5-byte records straight into the send buffers, the part of every destination rank is
+// one contiguous run.  Receiver (a table that is the window of its buckets, KQ_OPT_BUCKET_WINDOW): the runs of all peers
+// are (peer, bucket) segments of its bucket -> region levels, so the received records enter the ordinary narrow path.
+// 5 bytes per record cross xGMI.  kq_emit_packed_dev / kq_insert_packed_dev remain for k = 22..28 and small tables.
 // (peer q, bucket b) run j = q * 256 + b of the received array -> input segment b * n_peers + q of the receive levels
 __global__ void k_sharded_segments(const unsigned long long* __restrict__ start /*exclusive scan of the counts, peer-major*/,
                                    const unsigned long long* __restrict__ counts, uint32_t n_peers,
