@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--workload", choices=["human", "cfg1"], default="human")
     ap.add_argument("--genome-mbp", type=float, default=1000.0, help="human workload: genome size (3000 = BASELINE configs[2] in full)")
     ap.add_argument("--pending-bytes", type=int, default=-1, help="KQ_OPT_PENDING_BYTES (-1 auto, 0 = one table pass per slice)")
+    ap.add_argument("--slice-kmers", type=int, default=0, help="KQ_OPT_SLICE_KMERS (0 = the library's choice)")
     ap.add_argument("--reads", type=int, default=N_READS, help="cfg1: reads per GPU (default = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="human workload: skip the configs1 / lookup / union objects")
@@ -147,6 +148,8 @@ def run_human(args, dev, world=1, rank=0):
         free_b, total_b = device_memory(dev.index)
         pending = int(min(free_b - total_b // 8 if free_b > total_b // 4 else free_b // 2, 4 * db.info()["table_bytes"]))
     db.set_option("pending_bytes", pending)
+    if args.slice_kmers:
+        db.set_option("slice_kmers", args.slice_kmers)
 
     def barrier():
         if world > 1:
@@ -209,8 +212,10 @@ def run_human(args, dev, world=1, rank=0):
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         tj = json.load(open(tp))
-        if tj.get("workload") == f"human-{int(args.genome_mbp)}mbp-{steps}steps":
-            traffic = tj.get("hbm_bytes_per_launch")
+        # measured on the same workload (possibly cut into a different number of steps: the traffic is per k-mer, the
+        # table passes are the same -- one for the whole read set)
+        if tj.get("genome_mbp") == int(args.genome_mbp) and tj.get("hbm_bytes_per_kmer") and world == 1:
+            traffic = round(tj["hbm_bytes_per_kmer"] * kmers_per_step)
     out = {
         "metric": f"distinct+total k-mers/sec at k={k} (count path)", "value": value, "unit": "k-mers/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,

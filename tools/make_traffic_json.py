@@ -44,7 +44,8 @@ def main():
         tw += wb
     reads = int(mbp * 1e6 * 30 / 150) // steps * steps
     kmers_per_step = reads // steps * 130
-    out = {"workload": f"human-{mbp}mbp-{steps}steps",
+    out = {"workload": f"human-{mbp}mbp-{steps}steps", "genome_mbp": mbp, "kmers_per_step": kmers_per_step,
+           "hbm_bytes_per_kmer": (tf + tw) / steps / kmers_per_step,
            "what": f"configs[2] shape, {mbp} Mbp genome, 30x 150 bp reads in {steps} batches of {kmers_per_step} k-mers, k=21 (bench.py default workload)",
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps S --warmup 0 --no-cpu-baseline "
                      "--no-extras`; all dispatches of the count kernels summed and divided by S; FETCH_SIZE x 2 (gfx950), WRITE_SIZE as is",
