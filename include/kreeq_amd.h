@@ -164,13 +164,27 @@ int  kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len);
 /* Pipelined host ingest (what gfalibs' loadKmers reader thread + readBatches queue are to the reference, src/input.cpp:95-96):
  * kq_count_batch_async enqueues the host-to-device copy of a batch on a copy stream and its count behind it, and returns
  * at once; copies overlap the counting of earlier batches (a small ring of device staging buffers).  `bases` should come
- * from kq_host_alloc (pinned memory: the copy is a DMA at PCIe rate); the buffer may be refilled once kq_host_wait(ticket)
- * has returned.  Calls on one handle must still be serialised (a mutex around kq_count_batch_async is enough: it does
- * not block on the GPU).  kq_sync() drains everything. */
+ * from kq_host_alloc (page-locked memory: the copy is a DMA at PCIe rate, 50+ GB/s here; a copy out of pageable memory the
+ * runtime has not seen before costs ~1 ms per MiB for locking its pages) and be REUSED: a few buffers shared by all producer
+ * threads beat a buffer per thread.  The buffer may be refilled once kq_host_wait(ticket)
+ * has returned.  kq_count_batch_async may be called from several threads at once on one handle (the only entry point
+ * that may; the calls take turns inside, none of them waits for the GPU); no other call on the handle may run concurrently
+ * with them.  kq_sync() drains everything. */
 void* kq_host_alloc(uint64_t bytes);
 void  kq_host_free(void* p);
 int  kq_count_batch_async(kq_handle* h, const char* bases, uint64_t len, uint64_t* ticket);
 int  kq_host_wait(kq_handle* h, uint64_t ticket);
+
+/* 2-bit packed input (the "2-bit packing" step of the reference's kcount ancestry, moved in front of PCIe): kq_pack_bases
+ * (host, no GPU) turns `len` bytes of bases + separators into ceil(len / 16) units of one u32 of 2-bit codes (base i of the
+ * unit at bits 2i; A C G T = 0 1 2 3, case-blind) and one u16 of invalid-base bits (anything but ACGT/acgt -- read
+ * separators, N -- and the positions behind `len` in the last unit).  That is the tile scanner's own format: 6 bytes per
+ * 16 bases cross PCIe instead of 16, and the count kernels skip the ASCII conversion.  kq_count_packed_dev /
+ * kq_count_packed_async count such a batch exactly like kq_count_batch_dev / kq_count_batch_async count its ASCII form
+ * (same tickets, same threading rule; `codes` and `inv` may be refilled once kq_host_wait(ticket) has returned). */
+void kq_pack_bases(const char* bases, uint64_t len, uint32_t* codes, uint16_t* inv);
+int  kq_count_packed_dev(kq_handle* h, const uint32_t* d_codes, const uint16_t* d_inv, uint64_t n_bases);
+int  kq_count_packed_async(kq_handle* h, const uint32_t* codes, const uint16_t* inv, uint64_t n_bases, uint64_t* ticket);
 
 /* Hot loop 1 only (DBG::hashSequences :75-113): the (key, edge byte) records of a batch in
  * sequence order; edge byte layout = edgeBit (include/kreeq.h:6-18).  *n_out = number of records

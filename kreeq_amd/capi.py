@@ -13,7 +13,7 @@ DBGBASE_DTYPE = np.dtype([("fw", "<u4"), ("bw", "<u4"), ("cov", "<u4"), ("isFw",
 
 # every symbol include/kreeq_amd.h declares
 SYMBOLS = ["kq_create", "kq_destroy", "kq_clear", "kq_set_option", "kq_get_profile", "kq_set_stream", "kq_get_stream", "kq_sync", "kq_flush", "kq_get_info", "kq_last_error",
-           "kq_abi_version", "kq_device_available", "kq_device_memory", "kq_count_batch", "kq_count_batch_dev", "kq_host_alloc", "kq_host_free", "kq_count_batch_async", "kq_host_wait", "kq_emit_records",
+           "kq_abi_version", "kq_device_available", "kq_device_memory", "kq_count_batch", "kq_count_batch_dev", "kq_host_alloc", "kq_host_free", "kq_count_batch_async", "kq_host_wait", "kq_pack_bases", "kq_count_packed_dev", "kq_count_packed_async", "kq_emit_records",
            "kq_emit_partitioned_dev", "kq_emit_packed_dev", "kq_insert_packed_dev", "kq_emit_sharded_dev", "kq_insert_sharded_dev", "kq_insert_records", "kq_insert_records_dev", "kq_summary", "kq_histogram",
            "kq_lookup_sequence", "kq_lookup_sequence_dev", "kq_lookup_keys", "kq_branch_scan", "kq_merge", "kq_import", "kq_export"]
 
@@ -98,6 +98,10 @@ def load():
     L.kq_host_free.restype = None
     L.kq_count_batch_async.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.kq_host_wait.argtypes = [vp, u64]
+    L.kq_pack_bases.argtypes = [vp, u64, vp, vp]
+    L.kq_pack_bases.restype = None
+    L.kq_count_packed_dev.argtypes = [vp, vp, vp, u64]
+    L.kq_count_packed_async.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.kq_emit_records.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]
     L.kq_emit_partitioned_dev.argtypes = [vp, vp, u64, ci, vp, vp, u64, vp]
     L.kq_emit_packed_dev.argtypes = [vp, vp, u64, ci, vp, u64, vp]
@@ -126,6 +130,15 @@ def _check(rc):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def pack_bases(bases: bytes):
+    """-> (codes u32[ceil(n/16)], inv u16[ceil(n/16)]): the 2-bit packed form of a batch (kq_pack_bases; host only)"""
+    buf = np.frombuffer(bases, dtype=np.uint8)
+    units = (len(buf) + 15) // 16
+    codes, inv = np.zeros(max(units, 1), dtype=np.uint32), np.zeros(max(units, 1), dtype=np.uint16)
+    load().kq_pack_bases(_p(buf) if len(buf) else None, len(buf), _p(codes), _p(inv))
+    return codes[:units], inv[:units]
 
 
 def device_available():
@@ -202,6 +215,15 @@ class KreeqDB:
         on before the buffer is refilled"""
         t = C.c_uint64(0)
         _check(load().kq_count_batch_async(self._h, C.c_void_p(host_ptr), n, C.byref(t)))
+        return t.value
+
+    def count_packed_dev(self, codes_ptr, inv_ptr, n_bases):
+        _check(load().kq_count_packed_dev(self._h, C.c_void_p(codes_ptr), C.c_void_p(inv_ptr), n_bases))
+
+    def count_packed_async(self, codes_ptr, inv_ptr, n_bases):
+        """pipelined ingest of a 2-bit packed batch (pack_bases); returns the ticket to wait on before the arrays are refilled"""
+        t = C.c_uint64(0)
+        _check(load().kq_count_packed_async(self._h, C.c_void_p(codes_ptr), C.c_void_p(inv_ptr), n_bases, C.byref(t)))
         return t.value
 
     def host_wait(self, ticket):

@@ -332,22 +332,35 @@ __device__ __forceinline__ void convert16(const uint4& v, bool all_in, int64_t g
     }
 }
 
-// global half of a tile load: this lane's 16 bytes of the tile's 4096-byte window (zeros outside)
-__device__ __forceinline__ uint4 tile_fetch(const uint8_t* __restrict__ ab, int64_t lo_valid, int64_t hi_valid, uint64_t tile) {
+// global half of a tile load: this lane's 16 bytes of the tile's 4096-byte window (zeros outside).
+// PACKED input (pinv != nullptr; kq_pack_bases, include/kreeq_amd.h): `ab` is the array of 2-bit codes, one u32 per 16 bases
+// (base i at bits 2i), pinv the array of invalid-base masks, one u16 per 16 bases -- the scanner's own LDS format, 6 bytes
+// per 16 bases over PCIe instead of 16; the lane's unit comes back in v.x / v.y and tile_store skips the conversion.
+__device__ __forceinline__ uint4 tile_fetch(const uint8_t* __restrict__ ab, int64_t lo_valid, int64_t hi_valid, uint64_t tile,
+                                            const uint16_t* __restrict__ pinv = nullptr) {
     const int64_t g = (int64_t)(tile * TILE_STARTS) - 16 + 16 * (int)threadIdx.x;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (g + 16 > lo_valid && g < hi_valid) v = *reinterpret_cast<const uint4*>(ab + g);
+    if (g + 16 > lo_valid && g < hi_valid) {
+        if (pinv) { v.x = reinterpret_cast<const uint32_t*>(ab)[g >> 4]; v.y = pinv[g >> 4]; }      // (g is a multiple of 16, >= 0 here)
+        else v = *reinterpret_cast<const uint4*>(ab + g);
+    }
     return v;
 }
 // LDS half: convert to the 2-bit code stream + invalid-base bit stream (ends with a barrier)
 __device__ __forceinline__ void tile_store(const uint4& v, int64_t lo_valid, int64_t hi_valid, uint64_t tile,
-                                           uint32_t* s_codes, uint32_t* s_inv) {
+                                           uint32_t* s_codes, uint32_t* s_inv, bool packed = false) {
     const int tid = threadIdx.x;
     const int64_t g = (int64_t)(tile * TILE_STARTS) - 16 + 16 * tid;
     uint32_t codes = 0, inv = 0xFFFFu;
     if (g + 16 > lo_valid && g < hi_valid) {
         bool all_in = (g >= lo_valid) && (g + 16 <= hi_valid);
-        convert16(v, all_in, g, lo_valid, hi_valid, codes, inv);
+        if (packed) {
+            codes = v.x; inv = v.y & 0xFFFFu;
+            if (!all_in) {
+#pragma unroll
+                for (int b = 0; b < 16; ++b) { const int64_t p = g + b; if (p < lo_valid || p >= hi_valid) inv |= 1u << b; }
+            }
+        } else convert16(v, all_in, g, lo_valid, hi_valid, codes, inv);
     }
     s_codes[tid] = codes;
     s_inv[tid] = inv;
@@ -355,8 +368,8 @@ __device__ __forceinline__ void tile_store(const uint4& v, int64_t lo_valid, int
 }
 // loads + converts one tile's 4096-byte window into LDS (ends with a barrier)
 __device__ __forceinline__ void tile_load(const uint8_t* __restrict__ ab, int64_t lo_valid, int64_t hi_valid, uint64_t tile,
-                                          uint32_t* s_codes, uint32_t* s_inv) {
-    tile_store(tile_fetch(ab, lo_valid, hi_valid, tile), lo_valid, hi_valid, tile, s_codes, s_inv);
+                                          uint32_t* s_codes, uint32_t* s_inv, const uint16_t* __restrict__ pinv = nullptr) {
+    tile_store(tile_fetch(ab, lo_valid, hi_valid, tile, pinv), lo_valid, hi_valid, tile, s_codes, s_inv, pinv != nullptr);
 }
 
 // This lane's 16 consecutive k-mer starts of the loaded tile.  The forward word and its reverse
@@ -456,13 +469,13 @@ __device__ __forceinline__ uint32_t tile_lane_count(const uint32_t* s_inv, int k
 inline __host__ __device__ uint64_t n_tiles_of(uint64_t lead, uint64_t len) { return (lead + len + TILE_STARTS - 1) / TILE_STARTS; }
 
 template <class F>
-__device__ __forceinline__ void scan_tiles(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k, F&& f) {
+__device__ __forceinline__ void scan_tiles(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k, F&& f, const uint16_t* __restrict__ pinv = nullptr) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
     const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
     const uint64_t n_tiles = n_tiles_of(lead, len);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv, pinv);
         tile_lane_scan(s_codes, s_inv, lo_valid, tile, k, f);
         __syncthreads();
     }

@@ -20,7 +20,8 @@ using namespace kq;
 // K1+K2 fused: hashSequences (src/graph-builder.cpp:75-113) + processBuffers (:160-206) without
 // materialising the 9-byte records: 1 B/base streamed in, random RMW on the table.
 __global__ __launch_bounds__(TILE_THREADS) void k_count_direct(TableView t, const uint8_t* __restrict__ ab,
-                                                                uint64_t lead, uint64_t len, int k, EmitRange er, PartCfg filt) {
+                                                                uint64_t lead, uint64_t len, int k, EmitRange er, PartCfg filt,
+                                                                const uint16_t* __restrict__ pinv /*packed input (tile_fetch) or null*/) {
     uint32_t n_new = 0;
     uint64_t n_kmers = 0;
     scan_tiles(ab, lead, len, k, [&](uint64_t pos, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_count_direct(TableView t, cons
         uint32_t ins = 0;
         if (table_add(t, table_hash(key, (uint32_t)k), 1, edge_pack(is_fw, prev, next), nullptr, &ins)) ++n_kmers;
         n_new += ins;
-    });
+    }, pinv);
     uint64_t a = block_sum(n_new), b = block_sum(n_kmers);
     if (threadIdx.x == 0) {
         if (a) atomicAdd(&t.st->slots_used, (unsigned long long)a);
@@ -144,7 +145,8 @@ __device__ __forceinline__ uint32_t p1_bin_of(const PartCfg& cfg, uint64_t key, 
 // k-dependent shift and mask of the 16 scan steps and of the hash folds to an immediate)
 template <int BINMODE, int KC>
 __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k_arg,
-                                                          PartCfg cfg, EmitRange er, uint32_t g1, unsigned long long* __restrict__ m1) {
+                                                          PartCfg cfg, EmitRange er, uint32_t g1, unsigned long long* __restrict__ m1,
+                                                          const uint16_t* __restrict__ pinv /*packed input or null*/) {
     const int k = KC ? KC : k_arg;
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
     const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
     const uint64_t n_tiles = n_tiles_of(lead, len);
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv);         // barrier inside (also covers the zeroing above)
+        tile_load(ab, lo_valid, hi_valid, tile, s_codes, s_inv, pinv);   // barrier inside (also covers the zeroing above)
         tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int, bool valid, uint64_t fw, uint64_t rv, uint32_t, uint32_t) {
             if (valid) {
                 const uint64_t key = fw < rv ? fw : rv;
@@ -179,7 +181,8 @@ __global__ void k_p1_offsets(const unsigned long long* __restrict__ m1, const un
 template <int FMT, int NBC, int BINMODE, int KC>
 __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 : 2) void k_p1_scatter(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k_arg,
                                                              PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
-                                                             uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt) {
+                                                             uint64_t* __restrict__ recs, uint8_t* __restrict__ recs_aux, int aux_fmt,
+                                                             const uint16_t* __restrict__ pinv /*packed input or null*/) {
     __shared__ uint32_t s_codes[TILE_THREADS];
     __shared__ uint32_t s_inv[TILE_THREADS];
     constexpr bool WIDE = FMT == FMT_WIDE, NARROW = FMT == FMT_NARROW, TOP8 = FMT == FMT_TOP8;
@@ -193,11 +196,11 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
 #ifdef KQ_MS_STAMPS
     if (threadIdx.x == 0) s.stamp_on = 0;
 #endif
-    uint4 nxt = tile_fetch(ab, lo_valid, hi_valid, blockIdx.x);
+    uint4 nxt = tile_fetch(ab, lo_valid, hi_valid, blockIdx.x, pinv);
     landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w);         // see k_lv_scatter: keeps the loop header free of a store-draining wait
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_store(nxt, lo_valid, hi_valid, tile, s_codes, s_inv);        // barrier inside (covers the cursor init)
-        if (tile + gridDim.x < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + gridDim.x);   // in flight during the split
+        tile_store(nxt, lo_valid, hi_valid, tile, s_codes, s_inv, pinv != nullptr);        // barrier inside (covers the cursor init)
+        if (tile + gridDim.x < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + gridDim.x, pinv);   // in flight during the split
         uint64_t rec[MS_ITEMS];
         uint32_t aux[MS_ITEMS], bin[MS_ITEMS];
         tile_lane_scan_all(s_codes, s_inv, lo_valid, tile, k, er, [&](int i, bool valid, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {

@@ -7,7 +7,9 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -84,12 +86,13 @@ struct kq_handle {
     int64_t pend_budget = -1;            // KQ_OPT_PENDING_BYTES: -1 auto, 0 = apply every slice at once
     uint64_t table_passes = 0;           // k_count_regions passes so far
     // pipelined host ingest (kq_count_batch_async): copies on their own stream into a ring of device staging buffers
-    static constexpr int IN_SLOTS = 3, IN_TICKETS = 4096;
+    static constexpr int IN_SLOTS = 3, IN_TICKETS = 512;
     hipStream_t copy_stream = nullptr;
     void* in_buf[IN_SLOTS] = {nullptr, nullptr, nullptr}; size_t in_bytes[IN_SLOTS] = {0, 0, 0};
     hipEvent_t in_consumed[IN_SLOTS] = {nullptr, nullptr, nullptr};      // the count that read the slot has been enqueued and finished
     std::vector<hipEvent_t> in_copied;   // ring of "copy of ticket t done" events
     uint64_t in_next = 0;
+    std::mutex in_m;                     // kq_count_batch_async may be called from several threads: the calls take turns
     bool test_fail_plan = false;         // KQ_OPT_TEST_FAIL_PLAN: the next partition plan fails with KQ_ERR_NOMEM (failure-path tests)
     void* hot = nullptr; size_t hot_bytes = 0;         // k_count_regions' list of skewed regions
 
@@ -636,12 +639,12 @@ static void marks_reset(kq_handle* h) {
 }
 
 static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er, uint64_t* out,
-                   uint8_t* out_aux, int aux_fmt) {
+                   uint8_t* out_aux, int aux_fmt, const uint16_t* pinv = nullptr /*packed input: ab = the code words (tile_fetch)*/) {
     // plain table split (no owner split, no map-range filter): branch-free bin functions
     const bool plain = cfg.mode == 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;
     const bool owner_plain = cfg.mode == 1 && cfg.map_mask != 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;   // multi-GPU owner split
     const int binmode = owner_plain ? 3 : !plain ? 0 : cfg.narrow ? 2 : 1;
-#define KQ_P1H(B, K) hipLaunchKernelGGL((k_p1_hist<B, K>), dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1)
+#define KQ_P1H(B, K) hipLaunchKernelGGL((k_p1_hist<B, K>), dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1, pinv)
     if (binmode == 2) { if (h->k == 21) KQ_P1H(2, 21); else KQ_P1H(2, 0); }
     else if (binmode == 1) { if (h->k == 31) KQ_P1H(1, 31); else KQ_P1H(1, 0); }
     else if (binmode == 3) { if (h->k == 21) KQ_P1H(3, 21); else KQ_P1H(3, 0); }
@@ -651,7 +654,7 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     hipLaunchKernelGGL(k_p1_offsets, dim3((cfg.n_coarse + 256) / 256), dim3(256), 0, h->stream, p->m1, p->total, cfg, p->g1, p->seg_off);
     mark(h, "k_p1_hist+scan");
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
-#define KQ_P1S(W, N, B, K) hipLaunchKernelGGL((k_p1_scatter<W, N, B, K>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt)
+#define KQ_P1S(W, N, B, K) hipLaunchKernelGGL((k_p1_scatter<W, N, B, K>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt, pinv)
     if (cfg.narrow && h->k > PART_MAX_K) { if (plain && h->k == 31) KQ_P1S(FMT_TOP8, 512, 2, 31); else if (plain) KQ_P1S(FMT_TOP8, 512, 2, 0); else KQ_P1S(FMT_TOP8, 512, 0, 0); }
     else if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1S(FMT_NARROW, 512, 2, 21); else if (plain) KQ_P1S(FMT_NARROW, 512, 2, 0); else KQ_P1S(FMT_NARROW, 512, 0, 0); }     // 256 buckets
     else if (out_aux && plain && h->k == 31) { if (small) KQ_P1S(FMT_WIDE, 512, 1, 31); else KQ_P1S(FMT_WIDE, NB_MAX, 1, 31); }   // the HiFi k
@@ -900,7 +903,7 @@ static int pend_or_apply(kq_handle* h, const P3Set& set, int fmt, int aux_fmt, b
 }
 
 // partitioned count of one batch of bases: P1 (coarse split) -> P2 (region split) -> a pending set for P3 (LDS regions)
-static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er) {
+static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uint64_t len, EmitRange er, const uint16_t* pinv = nullptr) {
     PartPlan p;
     PartCfg c0; plan_cfg(h, &c0, true);
     int rc = plan_alloc(h, &p, len, n_tiles_of(lead, len), c0.n_coarse, true);
@@ -919,7 +922,7 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     if (leveled) { rc = arena_take(h, p.n_max, set_fmt, p.R, &set, &in_arena); if (rc) return rc; }
     marks_reset(h);
     mark(h, "start");
-    run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6);
+    run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6, pinv);
     if (p.fmt == FMT_NARROW || p.fmt == FMT_TOP8) {
         const uint64_t* sorted; const uint8_t* sorted_aux;
         run_narrow_levels(h, &p, &sorted, &sorted_aux, in_arena ? &set : nullptr, tight);
@@ -976,7 +979,8 @@ static int count_partitioned_records(kq_handle* h, const uint64_t* d_recs, const
     return pend_or_apply(h, set, p.fmt, aux_fmt, false);
 }
 
-int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
+// count a resident sequence: ASCII bytes (d_inv == nullptr) or the packed form (d_bases = the code words, d_inv = the masks)
+static int count_seq_dev(kq_handle* h, const char* d_bases, const uint16_t* d_inv, uint64_t len) {
     if (!h || (!d_bases && len)) return fail(KQ_ERR_INVALID, "null argument");
     HIPC(hipSetDevice(h->device));
     if (len < (uint64_t)h->k) return KQ_OK;                                  // src/graph-builder.cpp:60
@@ -1010,7 +1014,9 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
         const uint64_t sub_len = std::min(len, b + h->k) - sub_off;
         const EmitRange er{a - sub_off, b - sub_off};
         const uint8_t* ab; uint64_t lead;
-        aligned_view(d_bases + sub_off, &ab, &lead);
+        const uint16_t* pinv = nullptr;
+        if (d_inv) { ab = (const uint8_t*)(reinterpret_cast<const uint32_t*>(d_bases) + sub_off / 16); pinv = d_inv + sub_off / 16; lead = sub_off % 16; }
+        else aligned_view(d_bases + sub_off, &ab, &lead);
         // a table pass streams the whole table (2 x 16 B per slot) on top of ~37 B per record; the atomic path costs
         // ~95 ps per record whatever the table size (~480 B at the part's streaming rate): partition unless the table
         // is more than ~200 B per record the pass will apply -- this slice, plus what is pending already, times the
@@ -1029,7 +1035,7 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
             part = true;
         }
         if (part) {
-            rc = count_partitioned(h, ab, lead, sub_len, er);
+            rc = count_partitioned(h, ab, lead, sub_len, er, pinv);
             if (rc) return rc;
             continue;
         }
@@ -1038,10 +1044,32 @@ int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) {
         materialize(h);
         h->table_empty = false;
         hipLaunchKernelGGL(k_count_direct, dim3(grid_for(h, n_tiles_of(lead, sub_len), 1, 32)), dim3(TILE_THREADS), 0, h->stream,
-                           h->view(), ab, lead, sub_len, h->k, er, filt);
+                           h->view(), ab, lead, sub_len, h->k, er, filt, pinv);
         HIPC(hipGetLastError());
     }
     return KQ_OK;
+}
+int kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len) { return count_seq_dev(h, d_bases, nullptr, len); }
+int kq_count_packed_dev(kq_handle* h, const uint32_t* d_codes, const uint16_t* d_inv, uint64_t n_bases) {
+    if (!d_inv && n_bases) return fail(KQ_ERR_INVALID, "null argument");
+    return count_seq_dev(h, (const char*)d_codes, d_inv, n_bases);
+}
+// 16 bases -> one u32 of 2-bit codes (base i at bits 2i: A C G T = 0 1 2 3, case-blind) + one u16 of invalid-base bits
+// (anything but ACGT/acgt, and the positions behind `len` in the last unit): the tile scanner's own LDS format
+void kq_pack_bases(const char* bases, uint64_t len, uint32_t* codes, uint16_t* inv) {
+    static const struct Lut { uint8_t v[256]; Lut() { for (int i = 0; i < 256; ++i) v[i] = 4; v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; } } lut;
+    const uint64_t full = len / 16;
+    const uint8_t* b = (const uint8_t*)bases;
+    for (uint64_t u = 0; u < full; ++u, b += 16) {
+        uint32_t c = 0, m = 0;
+        for (int i = 0; i < 16; ++i) { const uint32_t x = lut.v[b[i]]; c |= (x & 3u) << (2 * i); m |= (x >> 2) << i; }
+        codes[u] = c; inv[u] = (uint16_t)m;
+    }
+    if (len % 16) {
+        uint32_t c = 0, m = 0xFFFFu;
+        for (uint64_t i = 0; i < len % 16; ++i) { const uint32_t x = lut.v[b[i]]; c |= (x & 3u) << (2 * i); if (!(x >> 2)) m &= ~(1u << i); }
+        codes[full] = c; inv[full] = (uint16_t)m;
+    }
 }
 int kq_count_batch(kq_handle* h, const char* bases, uint64_t len) {
     if (!h || (!bases && len)) return fail(KQ_ERR_INVALID, "null argument");
@@ -1057,16 +1085,24 @@ int kq_count_batch(kq_handle* h, const char* bases, uint64_t len) {
     return KQ_OK;
 }
 
+// page-locked host memory = ordinary pages registered with the runtime: measured on this box, hipHostRegister of 32 MiB
+// takes 0.2-0.5 ms and the copies then run at the same 50+ GB/s as from hipHostMalloc memory, whose allocation costs
+// 0.14 ms per MiB (and its release half of that again)
 void* kq_host_alloc(uint64_t bytes) {
-    void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const size_t n = ((size_t)(bytes ? bytes : 1) + 4095) & ~(size_t)4095;
+    void* p = aligned_alloc(4096, n);
+    if (!p) return nullptr;
+    if (hipHostRegister(p, n, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); free(p); return nullptr; }
     return p;
 }
-void kq_host_free(void* p) { if (p) (void)hipHostFree(p); }
+void kq_host_free(void* p) { if (p) { (void)hipHostUnregister(p); free(p); } }
 
-int kq_count_batch_async(kq_handle* h, const char* bases, uint64_t len, uint64_t* ticket) {
-    if (!h || !ticket || (!bases && len)) return fail(KQ_ERR_INVALID, "null argument");
+// shared by the ASCII and the packed entry point: copy (a [+ b]) into a staging slot, count behind the copy
+static int ingest_async(kq_handle* h, const void* a, size_t a_bytes, const void* b, size_t b_bytes, uint64_t n_bases, uint64_t* ticket) {
     HIPC(hipSetDevice(h->device));
+    // One caller at a time, copy included: concurrent copies from pageable memory on several streams were measured and are
+    // 3 x SLOWER than one after the other (HIP stages them through per-stream buffers it first has to set up)
+    std::lock_guard<std::mutex> lock(h->in_m);
     if (!h->copy_stream) {
         HIPC(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
         for (int i = 0; i < kq_handle::IN_SLOTS; ++i) HIPC(hipEventCreateWithFlags(&h->in_consumed[i], hipEventDisableTiming));
@@ -1079,19 +1115,32 @@ int kq_count_batch_async(kq_handle* h, const char* bases, uint64_t len, uint64_t
     *ticket = t;
     // the slot's previous reader must be done before it is overwritten (copy stream waits; the host does not)
     if (t >= (uint64_t)kq_handle::IN_SLOTS) HIPC(hipStreamWaitEvent(h->copy_stream, h->in_consumed[s], 0));
-    if (h->in_bytes[s] < len + 64) {
+    const size_t b_off = (a_bytes + 63) & ~(size_t)63, bytes = b_off + b_bytes;
+    if (h->in_bytes[s] < bytes + 64) {
         // growing a slot: nothing may still read the old buffer
         if (h->in_buf[s]) { HIPC(hipStreamSynchronize(h->copy_stream)); HIPC(hipStreamSynchronize(h->stream)); HIPC(hipFree(h->in_buf[s])); h->in_buf[s] = nullptr; h->in_bytes[s] = 0; }
-        const size_t want = (size_t)len + len / 4 + 4096;
+        const size_t want = bytes + bytes / 4 + 4096;
         HIPC(hipMalloc(&h->in_buf[s], want));
         h->in_bytes[s] = want;
     }
-    if (len) HIPC(hipMemcpyAsync(h->in_buf[s], bases, len, hipMemcpyHostToDevice, h->copy_stream));
+    char* d = (char*)h->in_buf[s];
+    if (a_bytes) HIPC(hipMemcpyAsync(d, a, a_bytes, hipMemcpyHostToDevice, h->copy_stream));
+    if (b_bytes) HIPC(hipMemcpyAsync(d + b_off, b, b_bytes, hipMemcpyHostToDevice, h->copy_stream));
     HIPC(hipEventRecord(copied, h->copy_stream));
     HIPC(hipStreamWaitEvent(h->stream, copied, 0));
-    int rc = kq_count_batch_dev(h, (const char*)h->in_buf[s], len);
+    int rc = count_seq_dev(h, d, b ? (const uint16_t*)(d + b_off) : nullptr, n_bases);
     HIPC(hipEventRecord(h->in_consumed[s], h->stream));
     return rc;
+}
+int kq_count_batch_async(kq_handle* h, const char* bases, uint64_t len, uint64_t* ticket) {
+    if (!h || !ticket || (!bases && len)) return fail(KQ_ERR_INVALID, "null argument");
+    return ingest_async(h, bases, len, nullptr, 0, len, ticket);
+}
+int kq_count_packed_async(kq_handle* h, const uint32_t* codes, const uint16_t* inv, uint64_t n_bases, uint64_t* ticket) {
+    if (!h || !ticket || ((!codes || !inv) && n_bases)) return fail(KQ_ERR_INVALID, "null argument");
+    const uint64_t units = (n_bases + 15) / 16;
+    if (!n_bases) return ingest_async(h, nullptr, 0, nullptr, 0, 0, ticket);
+    return ingest_async(h, codes, units * 4, inv, units * 2, n_bases, ticket);
 }
 int kq_host_wait(kq_handle* h, uint64_t ticket) {
     if (!h) return fail(KQ_ERR_INVALID, "null handle");

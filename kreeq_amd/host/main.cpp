@@ -7,8 +7,10 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -308,55 +310,125 @@ int passes_for(const UserInput& ui, uint64_t distinct) {
 // every range -- the GPU counterpart of the reference's map-range loop (computeMapRange /
 // loadMapRange, src/kreeq.cpp:59-74) and of its spill-to-disk behaviour under -m.  Only 1/passes of
 // the table is resident at a time; summary numbers and QV counters add up over the disjoint ranges.
-// Reads -> GPU: every parser thread fills pinned buffers of its own and submits them itself (kq_count_batch_async behind
-// a mutex: the call only enqueues a copy and the count kernels); a thread waits for the copy of a buffer to finish before
-// it refills it.  Parsing, PCIe copies and counting overlap without a consumer thread in between.
+// Reads -> GPU: the parser threads share a small POOL of page-locked buffers.  A thread takes a free buffer, fills it and
+// submits it itself (kq_count_batch_async: enqueues the DMA and the count kernels behind it, returns at once); the buffer
+// goes back to the pool when its copy has finished.  Parsing, PCIe copies and counting overlap without a consumer thread.
+// Why a pool: what costs on this path is not PCIe (a page-locked buffer copies at 50+ GB/s) but making host pages
+// DMA-able -- a copy out of a fresh pageable buffer takes 6-7 ms per 4-8 MB for exactly that, and buffers of their own for
+// every parser thread paid it once per buffer (35 of the 38 ms of ingesting a 310 MB FASTQ).  A pool is locked once
+// (kq_host_alloc: ~0.5 ms per buffer) and every copy after that runs at PCIe rate.
+// Optional (KQ_INGEST_PACK=1): the parser thread packs a buffer to 2 bits per base + a validity bit (kq_pack_bases) before
+// it submits it: 6 bytes per 16 bases cross PCIe instead of 16.
 struct GpuSink {
     kq_handle* h;
-    unsigned threads;
     size_t cap;
-    struct Slot { char* buf[2] = {nullptr, nullptr}; uint64_t ticket[2] = {0, 0}; bool busy[2] = {false, false}; int cur = 1; };
-    std::vector<Slot> slots;
+    bool packed;
+    struct Buf { char* ascii = nullptr; uint32_t* codes = nullptr; uint16_t* inv = nullptr; uint64_t ticket = 0; bool in_flight = false; };
+    std::vector<Buf> pool;
+    std::vector<int> free_list;                   // indices of buffers nobody holds
+    std::vector<int> flying;                      // submitted, oldest first
     std::mutex m;
-    std::string error;
-    bool pinned;          // page-locked buffers (DMA at PCIe rate, copies overlap everything) pay off from ~1 GB of input: locking pages
-                          // costs about as much as copying them once; below that, plain buffers and staged copies
-    GpuSink(kq_handle* handle, unsigned n_threads, size_t buffer_bytes, bool pin) : h(handle), threads(n_threads), cap(buffer_bytes), slots(n_threads), pinned(pin) {}
-    ~GpuSink() { for (auto& s : slots) for (char* b : s.buf) if (b) { if (pinned) kq_host_free(b); else free(b); } }
+    std::condition_variable cv;
+    std::atomic<long long> ns_wait{0}, ns_pack{0}, ns_call{0}, n_submit{0};     // KQ_INGEST_TRACE: where the threads spend their time
+    GpuSink(kq_handle* handle, unsigned n_buffers, size_t buffer_bytes, bool pack) : h(handle), cap(buffer_bytes), packed(pack), pool(n_buffers) {
+        for (unsigned i = 0; i < n_buffers; ++i) free_list.push_back((int)(n_buffers - 1 - i));
+    }
+    // a buffer gets its memory from the thread that first takes it: the page locking of the pool runs in parallel
+    void materialize(Buf& b) {
+        if (b.ascii) return;
+        // packed mode: the ASCII buffer never crosses PCIe (plain memory), the packed arrays do
+        b.ascii = packed ? (char*)malloc(cap) : (char*)kq_host_alloc(cap);
+        if (packed) { b.codes = (uint32_t*)kq_host_alloc((cap / 16 + 1) * 4); b.inv = (uint16_t*)kq_host_alloc((cap / 16 + 1) * 2); }
+        if (!b.ascii || (packed && (!b.codes || !b.inv))) throw std::runtime_error("read buffer allocation failed");
+    }
+    ~GpuSink() {
+        for (auto& b : pool) { if (packed) free(b.ascii); else kq_host_free(b.ascii); kq_host_free(b.codes); kq_host_free(b.inv); }
+    }
     BatchSink sink() {
         BatchSink bs;
-        bs.acquire = [this](unsigned t, size_t* c) {
-            Slot& s = slots[t];
-            s.cur ^= 1;
-            if (!s.buf[s.cur]) {
-                s.buf[s.cur] = pinned ? (char*)kq_host_alloc(cap) : (char*)malloc(cap);
-                if (!s.buf[s.cur]) throw std::runtime_error("read buffer allocation failed");
+        bs.acquire = [this](unsigned, size_t* c) {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::unique_lock<std::mutex> l(m);
+            for (;;) {
+                if (!free_list.empty()) break;
+                if (!flying.empty()) {                                // the oldest copy in flight: wait for it outside the lock
+                    const int i = flying.front();
+                    flying.erase(flying.begin());
+                    const uint64_t tk = pool[i].ticket;
+                    l.unlock();
+                    if (kq_host_wait(h, tk) != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error());
+                    l.lock();
+                    free_list.push_back(i);
+                    cv.notify_one();
+                    continue;
+                }
+                cv.wait(l);                                           // every buffer is being filled by another thread
             }
-            if (s.busy[s.cur]) { if (kq_host_wait(h, s.ticket[s.cur]) != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error()); s.busy[s.cur] = false; }
+            const int i = free_list.back();
+            free_list.pop_back();
+            l.unlock();
+            materialize(pool[i]);
+            ns_wait += (std::chrono::steady_clock::now() - t0).count();
             *c = cap;
-            return s.buf[s.cur];
+            return pool[i].ascii;
         };
-        bs.submit = [this](unsigned t, char* buf, size_t len) {
-            Slot& s = slots[t];
-            const int i = buf == s.buf[0] ? 0 : 1;
+        bs.submit = [this](unsigned, char* buf, size_t len) {
+            int i = 0;
+            while (pool[i].ascii != buf) ++i;
+            Buf& b = pool[i];
+            const auto t0 = std::chrono::steady_clock::now();
+            if (packed) kq_pack_bases(buf, len, b.codes, b.inv);
+            const auto t1 = std::chrono::steady_clock::now();
+            // no lock around the call: kq_count_*_async may be called from several threads (they take turns inside the library)
+            const int rc = packed ? kq_count_packed_async(h, b.codes, b.inv, len, &b.ticket) : kq_count_batch_async(h, buf, len, &b.ticket);
+            if (rc != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error());
+            ns_pack += (t1 - t0).count(); ns_call += (std::chrono::steady_clock::now() - t1).count(); ++n_submit;
             std::lock_guard<std::mutex> l(m);
-            if (kq_count_batch_async(h, buf, len, &s.ticket[i]) != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error());
-            s.busy[i] = true;
+            flying.push_back(i);
+            cv.notify_one();
         };
         return bs;
     }
 };
-void count_reads_file(kq_handle* h, const std::string& path, unsigned threads, uint64_t input_bytes) {
+void count_reads_file(kq_handle* h, const std::string& path, unsigned threads, uint64_t input_bytes, int device) {
     // buffers of 8-32 MiB: small enough that copies and counting of a 300 MB file overlap its parsing, large enough
-    // (>= 7 M k-mers) for the partitioned count path
-    const size_t cap = (size_t)std::min<uint64_t>(32ull << 20, std::max<uint64_t>(8ull << 20, input_bytes / (2 * (uint64_t)threads)));
-    threads = std::min(threads, 64u);                                 // 2 buffers per thread
-    GpuSink gs(h, threads, cap, input_bytes >= (1ull << 30));
+    // (>= 7 M k-mers) for the partitioned count path; the pool has a buffer per parser thread up to 16 and 2 to spare
+    size_t cap = (size_t)std::min<uint64_t>(32ull << 20, std::max<uint64_t>(8ull << 20, input_bytes / 64));
+    threads = std::min(threads, 64u);
+    unsigned n_buf = std::min(threads, 16u) + 2;
+    bool pack = false;
+    if (const char* e = getenv("KQ_INGEST_CAP_MB")) cap = (size_t)atol(e) << 20;      // tuning aids (tools/bench_extra/cli_ingest_*.py)
+    if (const char* e = getenv("KQ_INGEST_BUFFERS")) n_buf = (unsigned)std::max(2, atoi(e));
+    if (const char* e = getenv("KQ_INGEST_PACK")) pack = atoi(e) != 0;
+    // A job that knows its size sizes the pending-set arena once (the automatic arena starts small and doubles -- a table
+    // pass, a synchronisation and a reallocation every time -- which a 300 MB file pays four or five times): about one k-mer
+    // per two input bytes, 5 bytes per record, within half of the free HBM.  Larger inputs just fill it more than once.
+    {
+        uint64_t free_b = 0, total_b = 0;
+        if (kq_device_memory(device, &free_b, &total_b) != KQ_OK) free_b = 8ull << 30;
+        uint64_t want = std::max<uint64_t>(256ull << 20, input_bytes * 3);
+        if (const char* e = getenv("KQ_CLI_PENDING_MB")) want = (uint64_t)atol(e) << 20;
+        if (!getenv("KQ_CLI_PENDING_AUTO")) kq_or_die(kq_set_option(h, KQ_OPT_PENDING_BYTES, (int64_t)std::min<uint64_t>(want, free_b / 2)));
+    }
+    const auto t00 = std::chrono::steady_clock::now();
+    GpuSink gs(h, n_buf, cap, pack);
+    const auto t0 = std::chrono::steady_clock::now();
     read_batches_sink(path, threads, gs.sink());
+    const auto t1 = std::chrono::steady_clock::now();
     kq_or_die(kq_flush(h));                                          // everything is enqueued; the table pass may start
+    if (getenv("KQ_INGEST_TRACE"))
+        fprintf(stderr, "ingest: %u threads, %u buffers of %zu MiB, %lld submits, pool %.1f ms, wall %.1f ms + flush %.1f ms; thread-time sums: wait for a buffer %.1f ms, "
+                        "pack %.1f ms, submit calls %.1f ms\n", threads, n_buf, cap >> 20, (long long)gs.n_submit, (t0 - t00).count() * 1e-6, (t1 - t0).count() * 1e-6,
+                (std::chrono::steady_clock::now() - t1).count() * 1e-6, gs.ns_wait * 1e-6, gs.ns_pack * 1e-6, gs.ns_call * 1e-6);
 }
 
-unsigned parser_threads(const UserInput& ui) { return ui.maxThreads > 0 ? (unsigned)ui.maxThreads : std::max(1u, std::thread::hardware_concurrency()); }
+// -j, or one parser thread per 32 MB of input within [4, all cores]: the threads take turns submitting (one stream feeds the
+// GPU), and on a few hundred MB more of them only queue up behind each other (310 MB FASTQ: 8 threads 26-32 ms, 64: 38 ms)
+unsigned parser_threads(const UserInput& ui, uint64_t input_bytes = ~0ull) {
+    if (ui.maxThreads > 0) return (unsigned)ui.maxThreads;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (unsigned)std::min<uint64_t>(hw, std::max<uint64_t>(4, input_bytes >> 25));
+}
 
 int run_passes(Engine& e) {
     UserInput& ui = e.ui;
@@ -377,14 +449,14 @@ int run_passes(Engine& e) {
     if (want_validate && per_base_out) e.per_base.assign(e.genome.joined.size(), kq_dbgbase{});
     kq_stats sum{};
     std::vector<kq_entry> hc_all;
-    const unsigned threads = parser_threads(ui);
+    const unsigned threads = parser_threads(ui, bytes);
     for (int p = 0; p < ui.passes; ++p) {
         const int lo = (int)((long long)p * e.map_count / ui.passes), hi = (int)((long long)(p + 1) * e.map_count / ui.passes);
         verbose("Pass " + std::to_string(p + 1) + "/" + std::to_string(ui.passes) + ": maps [" + std::to_string(lo) + "," + std::to_string(hi) + ")");
         if (p) kq_or_die(kq_clear(e.h));
         kq_or_die(kq_set_option(e.h, KQ_OPT_COUNT_MAP_RANGE, (int64_t)lo | ((int64_t)hi << 16)));
         for (auto& f : ui.inReads)
-            count_reads_file(e.h, f, threads, bytes);
+            count_reads_file(e.h, f, threads, bytes, ui.device);
         kq_stats st;
         kq_or_die(kq_summary(e.h, &st));
         sum.total += st.total; sum.unique += st.unique; sum.distinct += st.distinct; sum.edges += st.edges;
@@ -434,7 +506,7 @@ int run(UserInput& ui) {
                 e.create(distinct_estimate(bytes));
                 verbose("Loading input reads.");
                 for (auto& f : ui.inReads)
-                    count_reads_file(e.h, f, parser_threads(ui), bytes);
+                    count_reads_file(e.h, f, parser_threads(ui, bytes), bytes, ui.device);
                 verbose("Reads loaded.");
             } else {                                                 // Input::loadGraph, src/input.cpp:56-74
                 if (ui.kmerDB.size() > 1) die("More than one DBG database provided. Merge them first. Exiting.");

@@ -967,3 +967,86 @@ def test_pipelined_host_ingest(kq, O):
     finally:
         for p in bufs:
             L.kq_host_free(p)
+
+
+def test_concurrent_host_ingest(kq, O):
+    """kq_count_batch_async from several threads at once (the CLI's parser threads submit their own buffers without a lock
+    of their own): pageable buffers, 16 threads over 8 staging slots, batches of different sizes incl. empty ones"""
+    import threading
+
+    k = 21
+    batches = [H.synth_reads(300 + 211 * i, 150, 300_000, seed=900 + i, err=0.01, n_rate=0.002)[0] for i in range(48)]
+    batches[5] = b""
+    batches[17] = b"ACGT"                                 # shorter than k
+    cpu = O.OracleDB(k, 128)
+    for b in batches:
+        if b:
+            cpu.count_batch(b, threads=8)
+    gpu = kq.KreeqDB(k, 128, capacity_hint=8_000_000)
+    arrs = [np.frombuffer(b, dtype=np.uint8).copy() if b else np.zeros(1, dtype=np.uint8) for b in batches]
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(t, len(batches), 16):
+                tk = gpu.count_batch_async(arrs[i].ctypes.data, len(batches[i]))
+                gpu.host_wait(tk)
+        except Exception as e:                           # noqa: BLE001 - reported below
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    gpu.sync()
+    assert gpu.summary() == cpu.summary()
+    assert H.entries_equal(gpu.export(), cpu.export())
+
+
+@pytest.mark.parametrize("k,path", [(21, "partitioned"), (21, "direct"), (31, "partitioned"), (11, "direct")])
+def test_packed_input(kq, O, k, path):
+    """2-bit packed batches (kq_pack_bases -> kq_count_packed_dev / _async) count exactly like their ASCII form: read
+    separators, N runs, lower case, lengths that are no multiple of 16, slices cutting inside a unit"""
+    import torch
+
+    from kreeq_amd import capi
+
+    rng = np.random.default_rng(3)
+    batches = [H.synth_reads(9000 + 37 * i, 150 - i, 300_000, seed=40 + i, err=0.01, n_rate=0.003)[0] for i in range(3)]
+    batches.append(b"acgtnACGT" * 7 + b"\n" + b"A" * (k - 1) + b"\n" + bytes(rng.choice(list(b"ACGTacgtN\n"), size=100_003).tolist()))
+    batches.append(b"ACGTAC")                               # shorter than k
+    # pack on the host, check the format against a plain restatement
+    codes, inv = capi.pack_bases(batches[3])
+    raw = np.frombuffer(batches[3], dtype=np.uint8)
+    lut = np.full(256, 4, dtype=np.uint8)
+    for ch, v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+        lut[ch] = v
+    c = lut[raw]
+    pad = (-len(c)) % 16
+    cc = np.concatenate([c, np.full(pad, 4, dtype=np.uint8)]).reshape(-1, 16)
+    want_codes = ((cc & 3).astype(np.uint32) << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+    want_inv = (((cc >> 2) & 1).astype(np.uint32) << np.arange(16, dtype=np.uint32)).sum(axis=1).astype(np.uint16)
+    assert np.array_equal(codes, want_codes) and np.array_equal(inv, want_inv)
+    cpu = O.OracleDB(k, 128)
+    gpu = kq.KreeqDB(k, 128, capacity_hint=6_000_000)
+    gpu.set_option("count_path", path)
+    gpu.set_option("slice_kmers", 300_001)                 # several slices per batch, cut inside 16-base units
+    dev = torch.device("cuda", 0)
+    for i, b in enumerate(batches):
+        cpu.count_batch(b, threads=8)
+        codes, inv = capi.pack_bases(b)
+        if i % 2 == 0:                                      # device-resident arrays
+            dc = torch.from_numpy(codes.view(np.int32).copy()).to(dev)
+            di = torch.from_numpy(inv.view(np.int16).copy()).to(dev)
+            torch.cuda.synchronize()
+            gpu.count_packed_dev(dc.data_ptr(), di.data_ptr(), len(b))
+            gpu.sync()
+        else:                                               # host arrays through the staging ring
+            tk = gpu.count_packed_async(codes.ctypes.data, inv.ctypes.data, len(b))
+            gpu.host_wait(tk)
+    gpu.sync()
+    assert gpu.summary() == cpu.summary()
+    assert H.entries_equal(gpu.export(), cpu.export())
+
