@@ -993,11 +993,19 @@ static int count_seq_dev(kq_handle* h, const char* d_bases, const uint16_t* d_in
     // slices grow up to 2^31 starts.  With pending sets the table pass is shared by many slices and the default holds.
     uint64_t slice = h->slice_kmers;
     if (h->pend_budget != 0 && !h->slice_user && kmers > slice) {
-        // large tables split records over up to 65536 segments before the last level: slices of up to 2^30 starts keep
-        // a few work units per segment (10 B of scratch per start for the default k)
-        slice = std::min<uint64_t>(1ull << 30, std::max<uint64_t>(slice, h->n_slots() / 4));
-        const uint64_t n_slices = (kmers + slice - 1) / slice;
-        slice = (kmers + n_slices - 1) / n_slices;           // equal slices
+        // large tables split records over up to 65536 segments before the last level: slices of up to 2^31 starts keep
+        // a few work units per segment and the number of pending sets per table pass low (one slice instead of two per
+        // 1.3e9-k-mer batch: table pass -3 %, step -1.8 % at 1000 Mbp); 10 B of scratch per start for the default k, so
+        // only as far as a quarter of the free HBM pays for it
+        const uint64_t base_slice = slice;
+        for (uint64_t cap : {1ull << 31, 1ull << 30}) {
+            slice = std::min<uint64_t>(cap, std::max<uint64_t>(base_slice, h->n_slots() / 4));
+            const uint64_t n_slices = (kmers + slice - 1) / slice;
+            slice = (kmers + n_slices - 1) / n_slices;           // equal slices
+            size_t free_b = 0, total_b = 0;
+            if (cap == (1ull << 30) || slice <= (1ull << 30)) break;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + h->part_bytes >= (size_t)11 * slice + ((size_t)2 << 30)) break;   // the plan takes ~10.2 B per start
+        }
     }
     if (h->pend_budget == 0 && !h->slice_user && kmers > slice && 2 * h->n_slots() > slice) {
         size_t free_b = 0, total_b = 0;
