@@ -166,6 +166,10 @@ class ShardedCounter:
         if self.world > map_count:
             raise ValueError("more ranks than maps")
         self.map_lo, self.map_hi = owner_range(self.rank, self.world, map_count)
+        # gloo has no all-to-all on device tensors: payloads of a device engine are staged through the host (tests that run
+        # several ranks on ONE GPU; the product's backend is nccl = RCCL, which moves device memory directly)
+        self.stage_host = (dist.is_initialized() and dist.get_backend(group) == "gloo"
+                           and getattr(getattr(engine, "device", None), "type", "cpu") != "cpu")
         # every rank must emit the record format every rank can insert: 5-byte records only if all tables allow them
         if self.world > 1 and hasattr(engine, "sharded5"):
             flag = torch.tensor([1 if engine.sharded5 else 0], dtype=torch.int64, device=getattr(engine, "device", torch.device("cpu")))
@@ -224,6 +228,8 @@ class ShardedCounter:
         """counts first (tiny; its result is needed on the host because all_to_all_single takes host split sizes), then
         one asynchronous all-to-all(v) per payload array into persistent receive buffers"""
         dev = payload[0].device
+        if self.stage_host:
+            return self._exchange_via_host(payload, send_counts, slot, meta)
         sc = torch.from_numpy(send_counts).to(dev, non_blocking=True)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)                 # how many records each peer sends me
@@ -240,6 +246,30 @@ class ShardedCounter:
             rmeta = self._recv_buffer(slot, "meta", meta.numel(), meta).view_as(meta)
             works.append(dist.all_to_all_single(rmeta, meta, group=self.group, async_op=True))
         return received, works, n_recv, rmeta
+
+    def _exchange_via_host(self, payload, send_counts, slot, meta):
+        """the same exchange with every array staged through host memory (gloo with a device engine, see __init__)"""
+        dev = payload[0].device
+        torch.cuda.current_stream(dev).synchronize()
+        sc = torch.from_numpy(send_counts)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        recv_counts = rc.numpy()
+        n_recv = int(recv_counts.sum())
+        received = []
+        for j, t in enumerate(payload):
+            r = torch.empty(n_recv, dtype=t.dtype)
+            dist.all_to_all_single(r, t.cpu(), output_split_sizes=recv_counts.tolist(), input_split_sizes=send_counts.tolist(), group=self.group)
+            rd = self._recv_buffer(slot, j, n_recv, t)
+            rd.copy_(r)
+            received.append(rd)
+        rmeta = None
+        if meta is not None:
+            rm = torch.empty(meta.shape, dtype=meta.dtype)
+            dist.all_to_all_single(rm, meta.cpu(), group=self.group)
+            rmeta = self._recv_buffer(slot, "meta", meta.numel(), meta).view_as(meta)
+            rmeta.copy_(rm)
+        return received, [], n_recv, rmeta
 
     def _count_batch(self, bases: torch.Tensor):
         if self.world == 1 and hasattr(self.engine, "count") and not self.sharded_path:
@@ -351,7 +381,7 @@ class ShardedCounter:
         from .capi import ENTRY_DTYPE
 
         parts = [np.ascontiguousarray(self.engine.export(*owner_range(d, self.world, self.map_count)), dtype=ENTRY_DTYPE) for d in range(self.world)]
-        dev = getattr(self.engine, "device", torch.device("cpu"))
+        dev = torch.device("cpu") if self.stage_host else getattr(self.engine, "device", torch.device("cpu"))
         send_counts = torch.tensor([p.nbytes for p in parts], dtype=torch.int64, device=dev)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
