@@ -82,11 +82,19 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # rehearsal of the N > 1 path on ONE GPU (never the measured configuration): KQ_BENCH_ONE_GPU=1 puts every rank on
+    # cuda:0 and KQ_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device
+    backend = os.environ.get("KQ_BENCH_BACKEND", "nccl")
+    if os.environ.get("KQ_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     out = run_human(args, dev, world, rank) if args.workload == "human" else run_cfg1(args, dev, world, rank, local_rank)
     if rank == 0:
         print(json.dumps(out), flush=True)
