@@ -25,7 +25,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.kq_abi_version() == 2
+    assert lib.kq_abi_version() == 3       # 3: bucket ownership of kq_emit_sharded_dev, windows, packed input
 
 
 def test_no_cpu_fallback(lib):
@@ -54,3 +54,24 @@ def test_product_does_not_touch_oracle():
                 if f.endswith((".py", ".h", ".hip", ".cpp", ".c")):
                     txt = open(os.path.join(dp, f), errors="replace").read()
                     assert "oracle" not in txt.lower(), os.path.join(dp, f)
+
+
+def test_pack_bases_host_only(lib):
+    """kq_pack_bases needs no GPU: 16 bases -> one u32 of 2-bit codes + one u16 of invalid-base bits"""
+    import numpy as np
+
+    rng = np.random.default_rng(11)
+    raw = bytes(rng.choice(list(b"ACGTacgtNn\n-"), size=10_007).tolist())
+    codes, inv = capi.pack_bases(raw)
+    assert len(codes) == len(inv) == (len(raw) + 15) // 16
+    lut = np.full(256, 4, dtype=np.uint8)
+    for ch, v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+        lut[ch] = v
+    c = lut[np.frombuffer(raw, dtype=np.uint8)]
+    cc = np.concatenate([c, np.full((-len(c)) % 16, 4, dtype=np.uint8)]).reshape(-1, 16)
+    want_codes = ((cc & 3).astype(np.uint64) << (2 * np.arange(16, dtype=np.uint64))).sum(axis=1).astype(np.uint32)
+    want_inv = (((cc >> 2) & 1).astype(np.uint32) << np.arange(16, dtype=np.uint32)).sum(axis=1).astype(np.uint16)
+    assert np.array_equal(codes, want_codes) and np.array_equal(inv, want_inv)
+    c0, i0 = capi.pack_bases(b"")
+    assert len(c0) == 0 and len(i0) == 0
+
