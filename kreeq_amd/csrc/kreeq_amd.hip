@@ -351,14 +351,19 @@ static int set_window(kq_handle* h, uint32_t lo, uint32_t hi) {
     uint64_t virt = round_regions(std::max<uint64_t>((alloc_now + nb - 1) / nb * 256, (uint64_t)NB_MAX), h->k);
     if (virt >= (1ull << 32)) return fail(KQ_ERR_INVALID, "bucket window too narrow for a table of %llu regions", (unsigned long long)alloc_now);
     HIPC(hipStreamSynchronize(h->stream));
-    if (h->slots) HIPC(hipFree(h->slots));
-    if (h->rstart) HIPC(hipFree(h->rstart));
-    h->slots = nullptr; h->rstart = nullptr;
-    h->n_regions = virt; h->win_lo = lo; h->win_hi = hi; h->windowed = !(lo == 0 && hi == 256);
-    int rc = alloc_main(h, virt, h->n_alloc_regions(), &h->slots, &h->rstart);
+    // the new table first: a failed allocation leaves the handle as it was
+    const bool windowed = !(lo == 0 && hi == 256);
+    const uint64_t alloc_new = windowed ? (uint64_t)(hi - lo) * (virt >> 8) : virt;
+    Slot* fresh = nullptr;
+    uint32_t* fresh_rs = nullptr;
+    int rc = alloc_main(h, virt, alloc_new, &fresh, &fresh_rs);
     if (rc) return rc;
-    h->slots_dirty = false;
     HIPC(hipStreamSynchronize(h->stream));
+    if (h->slots) (void)hipFree(h->slots);
+    if (h->rstart) (void)hipFree(h->rstart);
+    h->slots = fresh; h->rstart = fresh_rs;
+    h->n_regions = virt; h->win_lo = lo; h->win_hi = hi; h->windowed = windowed;
+    h->slots_dirty = false;
     return KQ_OK;
 }
 
