@@ -3,6 +3,7 @@ src/validate.cpp:52-122) against OUR `kreeq` CLI on the GPU, plus .kreeq / .bkwi
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from kreeq_amd import build
@@ -31,8 +32,8 @@ def remap(argv, golden_dbs):
     return out
 
 
-def run(cli, args, cwd=None):
-    p = subprocess.run([cli] + args, capture_output=True, text=True, cwd=cwd, timeout=300)
+def run(cli, args, cwd=None, env=None):
+    p = subprocess.run([cli] + args, capture_output=True, text=True, cwd=cwd, timeout=300, env=env)
     assert p.returncode == 0, p.stderr
     return p.stdout.split("\n")
 
@@ -347,3 +348,32 @@ def test_configs4_shape_hifi_k31_vcf(cli, tmp_path):
     want_vcf = V.correct_sequences(V.Graph(db.export(), k), recs, 40, 16)
     assert len(want_vcf) > 4 + 20
     assert got == want_vcf
+
+
+@pytest.mark.parametrize("knobs", [{"KQ_INGEST_PACK": "1"}, {"KQ_INGEST_PACK": "1", "KQ_INGEST_BUFFERS": "2", "KQ_INGEST_CAP_MB": "1"},
+                                   {"KQ_INGEST_BUFFERS": "2", "KQ_INGEST_CAP_MB": "1"}, {"KQ_CLI_PENDING_AUTO": "1"}])
+def test_cli_ingest_modes_agree(cli, tmp_path, knobs):
+    """the ingest pool in its corner configurations -- 2-bit packed submits, two small buffers shared by all parser threads,
+    the automatic (doubling) arena -- prints what the default configuration prints"""
+    import os
+
+    rng = np.random.default_rng(77)
+    genome = rng.integers(0, 4, 400_000)
+    fq = str(tmp_path / "r.fastq")
+    with open(fq, "wb") as f:
+        for i in range(30_000):
+            p0 = int(rng.integers(0, len(genome) - 150))
+            seq = np.frombuffer(b"ACGT", dtype=np.uint8)[genome[p0:p0 + 150]].copy()
+            if i % 97 == 0:
+                seq[int(rng.integers(0, 150))] = ord("N")
+            sb = seq.tobytes().lower() if i % 5 == 0 else seq.tobytes()
+            f.write(b"@r%d\n" % i + sb + b"\n+\n" + b"I" * 150 + b"\n")
+    fa = str(tmp_path / "g.fasta")
+    with open(fa, "wb") as f:
+        f.write(b">c\n" + np.frombuffer(b"ACGT", dtype=np.uint8)[genome].tobytes() + b"\n")
+    base = run(cli, ["validate", "-f", fa, "-r", fq, "-j", "7"])
+    env = dict(os.environ)
+    env.update(knobs)
+    got = run(cli, ["validate", "-f", fa, "-r", fq, "-j", "7"], env=env)
+    assert got == base and base[0] == "DBG Summary statistics:"
+
