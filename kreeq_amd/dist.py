@@ -284,9 +284,9 @@ class ShardedCounter:
             return int(send_counts.sum())
         # pipeline over chunks: the all-to-all of chunk i runs while chunk i-1 is inserted and chunk
         # i+1 is scanned (xGMI is point-to-point: the exchange costs about as much as the compute).
-        # A chunk stays below 2^27 bases (~1 GB of 8-byte records per all-to-all: larger messages are not safe with
-        # every collective backend); every rank must issue the same number of collectives, so the chunk count is the
-        # maximum over the ranks (one small all-reduce per batch)
+        # A chunk stays below 2^28 bases (1 GB of u32 records per all-to-all: messages beyond 4 GB lost records; on one GPU
+        # 2^28 measured 31.4 ms per 1.3e9 k-mers, 2^27 37.5, 2^29 51.2); every rank must issue the same number of
+        # collectives, so the chunk count is the maximum over the ranks (one small all-reduce per batch)
         n_total, pending = 0, None
         n_chunks = max(self.n_chunks, -(-bases.numel() // self.MAX_CHUNK_BASES))
         if self.world > 1:
@@ -326,7 +326,7 @@ class ShardedCounter:
                 dist.all_reduce(ctr, op=dist.ReduceOp.SUM, group=self.group)
             return ctr.cpu().numpy().astype(np.uint64)
 
-    MAX_CHUNK_BASES = 1 << 27
+    MAX_CHUNK_BASES = int(os.environ.get("KQ_EXCHANGE_MAX_BASES", str(1 << 28)))
     HIST_DENSE = 4096        # coverages below this travel as one dense all-reduce; the few above are gathered as pairs
 
     def histogram(self):
