@@ -220,7 +220,9 @@ int  kq_insert_packed_dev(kq_handle* h, const uint64_t* d_recs, uint64_t n);
  * levels directly.  The receiving handle is the window of its buckets (KQ_OPT_BUCKET_WINDOW; with one part: an ordinary
  * table) and must have >= 2048 regions; records of buckets outside its window are ignored.
  * (The reference's key % mapCount -- src/graph-builder.cpp:95 -- remains the layout of the database FILES: export filters
- * by map range on every shard.)  Buffers need room for len - k + 1 records.  kq_emit_sharded_dev synchronises. */
+ * by map range on every shard.)  Buffers need room for len - k + 1 records.  kq_emit_sharded_dev synchronises to fill
+ * part_counts; with part_counts == NULL it only enqueues (the part sizes are the row sums of d_bucket_counts: a caller that
+ * exchanges the counts anyway reads them in the same host round trip). */
 int  kq_emit_sharded_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts, uint32_t* d_recs, uint8_t* d_aux, uint64_t cap,
                          uint64_t* d_bucket_counts, uint64_t* part_counts);
 int  kq_insert_sharded_dev(kq_handle* h, const uint32_t* d_recs, const uint8_t* d_aux, uint64_t n, int n_peers, const uint64_t* d_bucket_counts);

@@ -256,8 +256,9 @@ class KreeqDB:
     def insert_packed_dev(self, recs_ptr, n):
         _check(load().kq_insert_packed_dev(self._h, C.c_void_p(recs_ptr), n))
 
-    def emit_sharded_dev(self, bases_ptr, n, n_parts, recs_ptr, aux_ptr, cap, bucket_counts_ptr):
-        counts = np.zeros(n_parts, dtype=np.uint64)
+    def emit_sharded_dev(self, bases_ptr, n, n_parts, recs_ptr, aux_ptr, cap, bucket_counts_ptr, sync=True):
+        """sync=False: only enqueues and returns None (the part sizes are the row sums of the device bucket counts)"""
+        counts = np.zeros(n_parts, dtype=np.uint64) if sync else None
         _check(load().kq_emit_sharded_dev(self._h, C.c_void_p(bases_ptr), n, n_parts, C.c_void_p(recs_ptr), C.c_void_p(aux_ptr), cap,
                                           C.c_void_p(bucket_counts_ptr), _p(counts)))
         return counts

@@ -1302,14 +1302,14 @@ __global__ void k_bucket_meta(const unsigned long long* __restrict__ seg_off, ui
 }
 int kq_emit_sharded_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_parts, uint32_t* d_recs, uint8_t* d_aux, uint64_t cap,
                         uint64_t* d_bucket_counts, uint64_t* part_counts) {
-    if (!h || !part_counts || !d_bucket_counts || n_parts < 1 || n_parts > 256 || (!d_bases && len))
+    if (!h || !d_bucket_counts || n_parts < 1 || n_parts > 256 || (!d_bases && len))
         return fail(KQ_ERR_INVALID, "bad argument");
     if (h->k > (int)NARROW_MAX_K) return fail(KQ_ERR_INVALID, "5-byte records need k <= %u (use kq_emit_packed_dev)", NARROW_MAX_K);
     HIPC(hipSetDevice(h->device));
-    for (int i = 0; i < n_parts; ++i) part_counts[i] = 0;
+    for (int i = 0; part_counts && i < n_parts; ++i) part_counts[i] = 0;
     const uint64_t n_groups = (uint64_t)n_parts << NARROW_CBITS;
     HIPC(hipMemsetAsync(d_bucket_counts, 0, n_groups * 8, h->stream));
-    if (len < (uint64_t)h->k) { HIPC(hipStreamSynchronize(h->stream)); return KQ_OK; }
+    if (len < (uint64_t)h->k) { if (part_counts) HIPC(hipStreamSynchronize(h->stream)); return KQ_OK; }
     if (len - h->k + 1 >= (1ull << 32) - 16) return fail(KQ_ERR_INVALID, "a bucket split handles fewer than 2^32 k-mer starts per call (got %llu): cut the batch", (unsigned long long)(len - h->k + 1));
     if (cap < len - h->k + 1 || !d_recs || !d_aux) return fail(KQ_ERR_CAPACITY, "record buffers too small: need room for %llu records", (unsigned long long)(len - h->k + 1));
     const uint8_t* ab; uint64_t lead;
@@ -1324,6 +1324,8 @@ int kq_emit_sharded_dev(kq_handle* h, const char* d_bases, uint64_t len, int n_p
     cfg.filt_lo = 0; cfg.filt_hi = cfg.map_count;
     run_p1(h, &p, cfg, ab, lead, len, EmitRange{0, ~0ull}, (uint64_t*)d_recs, d_aux, AUX_IDX6);
     hipLaunchKernelGGL(k_bucket_meta, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, h->stream, p.seg_off, (uint32_t)n_parts, (unsigned long long*)d_bucket_counts);
+    HIPC(hipGetLastError());
+    if (!part_counts) return KQ_OK;               // asynchronous: the caller takes the part sizes from the rows of d_bucket_counts
     std::vector<unsigned long long> off((size_t)(1u << NARROW_CBITS) + 1);
     HIPC(hipMemcpyAsync(off.data(), p.seg_off, off.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));

@@ -83,9 +83,13 @@ class GpuEngine:
         # geometry (>= 2048 regions of 2048 slots); else 8-byte packed records (k <= 28) or key + edge byte
         self.sharded5 = k <= 21 and self.db.info()["slots_total"] // 2048 >= 2048
 
-    def emit_partitioned(self, bases: torch.Tensor, n_parts: int, slot: int = 0):
+    lazy_counts = True      # emit_partitioned(..., lazy=True) may return counts=None: the part sizes are meta.sum(dim=1) on the device
+
+    def emit_partitioned(self, bases: torch.Tensor, n_parts: int, slot: int = 0, lazy: bool = False):
         """-> ([payload tensors grouped by owner part], per-part record counts).  `slot` selects one of
-        two send buffers, so a chunk can be scanned while the previous one is still being exchanged."""
+        two send buffers, so a chunk can be scanned while the previous one is still being exchanged.
+        lazy (5-byte records only): nothing is read back -- the payload tensors are the whole send buffers and counts is None;
+        the caller slices them once it knows the sizes (it exchanges the counts anyway: one host round trip instead of two)."""
         n = bases.numel()
         if self.sharded5:
             buf = self._send.get(("s5", slot))
@@ -94,7 +98,9 @@ class GpuEngine:
                        torch.empty((n_parts, 256), dtype=torch.int64, device=self.device))
                 self._send[("s5", slot)] = buf
             recs, aux, meta = buf
-            counts = self.db.emit_sharded_dev(bases.data_ptr(), n, n_parts, recs.data_ptr(), aux.data_ptr(), recs.numel(), meta.data_ptr())
+            counts = self.db.emit_sharded_dev(bases.data_ptr(), n, n_parts, recs.data_ptr(), aux.data_ptr(), recs.numel(), meta.data_ptr(), sync=not lazy)
+            if lazy:
+                return [recs, aux], None, meta
             tot = int(counts.sum())
             return [recs[:tot], aux[:tot]], counts.astype(np.int64), meta
         buf = self._send.get(slot)
@@ -219,8 +225,10 @@ class ShardedCounter:
         return buf[:n]
 
     @staticmethod
-    def _emit(engine, bases, world, slot=0):
+    def _emit(engine, bases, world, slot=0, lazy=False):
         """-> (payload tensors, per-part counts, meta): meta = per-(part, bucket) counts of the 5-byte format, else None"""
+        if lazy and getattr(engine, "lazy_counts", False) and getattr(engine, "sharded5", False):
+            return engine.emit_partitioned(bases, world, slot=slot, lazy=True)
         res = engine.emit_partitioned(bases, world, slot=slot)
         return res if len(res) == 3 else (res[0], res[1], None)
 
@@ -228,12 +236,24 @@ class ShardedCounter:
         """counts first (tiny; its result is needed on the host because all_to_all_single takes host split sizes), then
         one asynchronous all-to-all(v) per payload array into persistent receive buffers"""
         dev = payload[0].device
+        if send_counts is None and self.stage_host:                      # lazy emit: the part sizes are still on the device
+            send_counts = meta.sum(dim=1).cpu().numpy()
+            payload = [t[:int(send_counts.sum())] for t in payload]
         if self.stage_host:
             return self._exchange_via_host(payload, send_counts, slot, meta)
-        sc = torch.from_numpy(send_counts).to(dev, non_blocking=True)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)                 # how many records each peer sends me
-        recv_counts = rc.cpu().numpy()
+        if send_counts is None:
+            # lazy emit: send and receive counts come back in ONE host round trip
+            sc = meta.sum(dim=1)
+            rc = torch.empty_like(sc)
+            dist.all_to_all_single(rc, sc, group=self.group)
+            both = torch.stack([sc, rc]).cpu().numpy()
+            send_counts, recv_counts = both[0].copy(), both[1].copy()
+            payload = [t[:int(send_counts.sum())] for t in payload]
+        else:
+            sc = torch.from_numpy(send_counts).to(dev, non_blocking=True)
+            rc = torch.empty_like(sc)
+            dist.all_to_all_single(rc, sc, group=self.group)             # how many records each peer sends me
+            recv_counts = rc.cpu().numpy()
         n_recv = int(recv_counts.sum())
         received, works = [], []
         for j, t in enumerate(payload):
@@ -296,7 +316,7 @@ class ShardedCounter:
         chunks = self._cut_points(bases, n_chunks)               # exactly n_chunks (possibly empty) chunks on every rank
         for i, (lo, hi) in enumerate(chunks):
             # send buffer i % 2: the exchange of chunk i-2 was waited for before chunk i-1 was started
-            payload, send_counts, meta = self._emit(self.engine, bases[lo:hi], self.world, slot=i % 2)
+            payload, send_counts, meta = self._emit(self.engine, bases[lo:hi], self.world, slot=i % 2, lazy=True)
             started = self._exchange_start(payload, send_counts, slot=i % 2, meta=meta)
             if pending is not None:
                 self._insert_received(pending)
