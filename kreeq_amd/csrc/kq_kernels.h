@@ -137,6 +137,9 @@ __device__ __forceinline__ uint32_t p1_col(uint32_t vb, uint32_t g1) { return (v
 // bits (narrow).  The specialised modes keep the 16 unrolled steps free of wave-uniform branches.
 template <int BINMODE>
 __device__ __forceinline__ uint32_t p1_bin_of(const PartCfg& cfg, uint64_t key, uint64_t h) {
+    // 4: hash-prefix bucket behind the map-range filter of a memory-bounded pass (KQ_OPT_COUNT_MAP_RANGE; map_count a power
+    // of two): one subtract + compare decides, rejected k-mers go to the discard bin
+    if (BINMODE == 4) return (((uint32_t)key & cfg.map_mask) - cfg.filt_lo < cfg.filt_hi - cfg.filt_lo) ? (uint32_t)(h >> (64 - NARROW_CBITS)) : cfg.n_coarse;
     return BINMODE == 3 ? ((((((uint32_t)key & cfg.map_mask) * (cfg.n_coarse >> cfg.owner_sub)) >> __popc(cfg.map_mask)) << cfg.owner_sub) |
                           (threadIdx.x & ((1u << cfg.owner_sub) - 1u)))         // owner rank x lane sub-bin; map_count a power of two, no filter
          : BINMODE == 2 ? (uint32_t)(h >> (64 - NARROW_CBITS)) : BINMODE == 1 ? (uint32_t)(hash_region(h, cfg.n_regions) >> cfg.g_shift) : p1_bin(cfg, key, h);
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
             if (valid) {
                 const uint64_t key = fw < rv ? fw : rv;
                 const uint32_t b = p1_bin_of<BINMODE>(cfg, key, table_hash(key, (uint32_t)k));
-                if (BINMODE != 0 || b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
+                if ((BINMODE != 0 && BINMODE != 4) || b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
             }
         });
         __syncthreads();

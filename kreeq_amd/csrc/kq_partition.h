@@ -234,9 +234,15 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     static_assert(THREADS * ITEMS <= S::tile, "round size");
     // FMT_NARROW: rec[i] is the staged word itself (u32 | bin << 32 | byte << 48, narrow_word()); aux[] and
     // bin[] are not read, which saves the caller 2 x ITEMS registers
+    // records of the discard bin (read separators, k-mers a map-range filter rejects: half or more of a tile in a map-range
+    // pass) take no rank: they are never staged, and their rank atomics would all hit ONE LDS counter and serialise
     uint32_t rank[ITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) rank[i] = atomicAdd(&s.hist[((FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i]) << rs) | sub], 1u);
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t b = FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i];
+        rank[i] = 0;
+        if (b != nb) rank[i] = atomicAdd(&s.hist[(b << rs) | sub], 1u);
+    }
     __syncthreads();
     KQ_MS_STAMP(s, 2);                            // rank atomics + barrier
     ms_scan<THREADS>(s, n_ctr);
@@ -246,7 +252,9 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     for (uint32_t b = tid; b < nb; b += THREADS) s.gbase[b] -= s.loff[b << rs];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const uint32_t p = s.loff[((FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i]) << rs) | sub] + rank[i];
+        const uint32_t b = FMT == FMT_NARROW ? narrow_word_bin(rec[i]) : bin[i];
+        if (b == nb) continue;                                          // discarded: not staged
+        const uint32_t p = s.loff[(b << rs) | sub] + rank[i];
         if (FMT == FMT_NARROW) {
             s.stage[p] = rec[i];                                        // one 8-byte write, no sub-dword traffic
         } else {
@@ -265,7 +273,7 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     uint64_t cv[ITEMS];
     if (FMT == FMT_NARROW) {
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) { cv[it] = s.stage[tid + it * THREADS]; cb[it] = narrow_word_bin(cv[it]); }
+        for (int it = 0; it < ITEMS; ++it) { cv[it] = s.stage[tid + it * THREADS]; cb[it] = tid + it * THREADS < total ? narrow_word_bin(cv[it]) : 0u; }   // (behind `total` the stage holds stale words)
     } else {
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) { const uint32_t j = tid + it * THREADS; cb[it] = j < total ? s.sbin[j] : 0u; cv[it] = s.stage[j]; }

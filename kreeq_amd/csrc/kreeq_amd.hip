@@ -125,7 +125,7 @@ static int grid_for(const kq_handle* h, uint64_t work_items, int per_block, int 
 static int ensure_buf(void** p, size_t* have, size_t need) {
     if (*have >= need) return KQ_OK;
     if (*p) { HIPC(hipFree(*p)); *p = nullptr; *have = 0; }
-    size_t sz = need + need / 4 + 4096;
+    size_t sz = need + std::min<size_t>(need / 4, (size_t)256 << 20) + 4096;      // geometric growth for small buffers, bounded slack for multi-GB ones
     HIPC(hipMalloc(p, sz));
     *have = sz;
     return KQ_OK;
@@ -648,11 +648,13 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     // plain table split (no owner split, no map-range filter): branch-free bin functions
     const bool plain = cfg.mode == 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;
     const bool owner_plain = cfg.mode == 1 && cfg.map_mask != 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;   // multi-GPU owner split
-    const int binmode = owner_plain ? 3 : !plain ? 0 : cfg.narrow ? 2 : 1;
+    const bool narrow_filt = cfg.mode == 0 && cfg.narrow && !plain && cfg.map_mask != 0 && h->k <= (int)NARROW_MAX_K;   // map-range pass on a bucketed table
+    const int binmode = owner_plain ? 3 : narrow_filt ? 4 : !plain ? 0 : cfg.narrow ? 2 : 1;
 #define KQ_P1H(B, K) hipLaunchKernelGGL((k_p1_hist<B, K>), dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1, pinv)
     if (binmode == 2) { if (h->k == 21) KQ_P1H(2, 21); else KQ_P1H(2, 0); }
     else if (binmode == 1) { if (h->k == 31) KQ_P1H(1, 31); else KQ_P1H(1, 0); }
     else if (binmode == 3) { if (h->k == 21) KQ_P1H(3, 21); else KQ_P1H(3, 0); }
+    else if (binmode == 4) { if (h->k == 21) KQ_P1H(4, 21); else KQ_P1H(4, 0); }
     else KQ_P1H(0, 0);
 #undef KQ_P1H
     scan_u64(h, p->m1, (uint64_t)cfg.n_coarse * p->g1 * P1_F, p->sums, p->total);
@@ -661,6 +663,7 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
 #define KQ_P1S(W, N, B, K) hipLaunchKernelGGL((k_p1_scatter<W, N, B, K>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt, pinv)
     if (cfg.narrow && h->k > PART_MAX_K) { if (plain && h->k == 31) KQ_P1S(FMT_TOP8, 512, 2, 31); else if (plain) KQ_P1S(FMT_TOP8, 512, 2, 0); else KQ_P1S(FMT_TOP8, 512, 0, 0); }
+    else if (narrow_filt)  { if (h->k == 21) KQ_P1S(FMT_NARROW, 512, 4, 21); else KQ_P1S(FMT_NARROW, 512, 4, 0); }
     else if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1S(FMT_NARROW, 512, 2, 21); else if (plain) KQ_P1S(FMT_NARROW, 512, 2, 0); else KQ_P1S(FMT_NARROW, 512, 0, 0); }     // 256 buckets
     else if (out_aux && plain && h->k == 31) { if (small) KQ_P1S(FMT_WIDE, 512, 1, 31); else KQ_P1S(FMT_WIDE, NB_MAX, 1, 31); }   // the HiFi k
     else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512, 0, 0); else KQ_P1S(FMT_WIDE, NB_MAX, 0, 0); }
@@ -924,10 +927,20 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     P3Set set; bool in_arena = false;
     const bool tight = tight_ok(h, p);
     const int set_fmt = tight ? FMT_TIGHT : p.fmt;
-    if (leveled) { rc = arena_take(h, p.n_max, set_fmt, p.R, &set, &in_arena); if (rc) return rc; }
+    // A map-range pass (KQ_OPT_COUNT_MAP_RANGE: the reference's memory-bounded mode, src/kreeq.cpp:59-74) keeps a fraction of
+    // the k-mers it scans: its pending set is sized by the record count P1 found, not by the starts of the slice, so that the
+    // arena holds as many RECORDS per table pass as it would without the filter (one small read-back per slice)
+    const bool filtered = p.cfg.filt_lo != 0 || p.cfg.filt_hi != p.cfg.map_count;
+    if (leveled && !filtered) { rc = arena_take(h, p.n_max, set_fmt, p.R, &set, &in_arena); if (rc) return rc; }
     marks_reset(h);
     mark(h, "start");
     run_p1(h, &p, p.cfg, ab, lead, len, er, p.recs1, a1, AUX_IDX6, pinv);
+    if (leveled && filtered) {
+        unsigned long long n_recs = 0;
+        HIPC(hipMemcpyAsync(&n_recs, p.total, sizeof n_recs, hipMemcpyDeviceToHost, h->stream));
+        HIPC(hipStreamSynchronize(h->stream));
+        rc = arena_take(h, std::min<uint64_t>(p.n_max, ((uint64_t)n_recs + 15) & ~7ull), set_fmt, p.R, &set, &in_arena); if (rc) return rc;
+    }
     if (p.fmt == FMT_NARROW || p.fmt == FMT_TOP8) {
         const uint64_t* sorted; const uint8_t* sorted_aux;
         run_narrow_levels(h, &p, &sorted, &sorted_aux, in_arena ? &set : nullptr, tight);

@@ -98,3 +98,30 @@ def reads_dev(genome, n_reads, read_len, gen, err=0.005, chunk=1_000_000):
         codes = torch.where(e, (codes + torch.randint(1, 4, (n, read_len), dtype=torch.uint8, device=dev, generator=gen)) & 3, codes)
         out[lo:lo + n, :read_len] = acgt[codes.long()]
     return out.reshape(-1)[:-1]
+
+
+def pack_dev(ascii_t, chunk_units=1 << 24):
+    """2-bit packed form of a read batch, made on the device: (codes int32[ceil(n/16)], inv int16[ceil(n/16)]) in the layout of
+    kq_pack_bases (include/kreeq_amd.h): base i of a unit at bits 2i (A C G T = 0 1 2 3, case-blind), invalid-base bit i for
+    anything else and for the positions behind the end.  3 bits per base instead of 8: what lets a whole 30x read set
+    of BASELINE configs[2] stay resident next to its table."""
+    import torch
+    dev = ascii_t.device
+    n = ascii_t.numel()
+    units = (n + 15) // 16
+    codes = torch.empty(units, dtype=torch.int32, device=dev)
+    inv = torch.empty(units, dtype=torch.int16, device=dev)
+    sh2 = (2 * torch.arange(16, device=dev, dtype=torch.int32))[None, :]
+    sh1 = torch.arange(16, device=dev, dtype=torch.int32)[None, :]
+    for lo in range(0, units, chunk_units):
+        hi = min(units, lo + chunk_units)
+        x = ascii_t[lo * 16:min(n, hi * 16)]
+        if x.numel() < (hi - lo) * 16:
+            x = torch.cat([x, torch.full(((hi - lo) * 16 - x.numel(),), 10, dtype=torch.uint8, device=dev)])
+        x = x.view(-1, 16).to(torch.int32)
+        u = x & 0xDF
+        ok = (u == 65) | (u == 67) | (u == 71) | (u == 84)
+        c = torch.where(ok, ((x >> 1) ^ (x >> 2)) & 3, torch.zeros_like(x))
+        codes[lo:hi] = (c << sh2).sum(1, dtype=torch.int32)          # disjoint bit fields: the sum is their OR (wraps into the sign bit)
+        inv[lo:hi] = ((~ok).to(torch.int32) << sh1).sum(1, dtype=torch.int32).to(torch.int16)
+    return codes, inv

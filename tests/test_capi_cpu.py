@@ -75,3 +75,18 @@ def test_pack_bases_host_only(lib):
     c0, i0 = capi.pack_bases(b"")
     assert len(c0) == 0 and len(i0) == 0
 
+
+
+def test_device_packer_matches_kq_pack_bases(lib):
+    """synth.pack_dev (the packer bench.py and the human-scale tests run on the device) writes kq_pack_bases' layout"""
+    import numpy as np
+    import torch
+
+    from kreeq_amd import synth
+
+    rng = np.random.default_rng(12)
+    for n in (1, 15, 16, 17, 4097, 100_003):
+        raw = rng.choice(np.frombuffer(b"ACGTacgtNn\n-", dtype=np.uint8), n).astype(np.uint8)
+        c, i = synth.pack_dev(torch.from_numpy(raw), chunk_units=1000)
+        c2, i2 = capi.pack_bases(raw.tobytes())
+        assert np.array_equal(c.numpy().view(np.uint32), c2) and np.array_equal(i.numpy().view(np.uint16), i2), n

@@ -1,8 +1,16 @@
 """BASELINE configs[2] shape (iid genome, 30x 150 bp reads with 0.5 % substitutions, k = 21, count + validate of the
 assembly = genome with 1e-4 substitutions) at 100 Mbp -- 1/30 of the human-scale job -- against the CPU oracle on the
-SAME batches: 2.6 x 10^9 read k-mers, ~3.5 x 10^8 distinct, a 16.7 GB table with a middle split level, pending record
-sets applied in one or two table passes.  Every summary number, the whole coverage histogram and the three QV
-counters must be identical.  (Larger scales are covered by bench.py's closed-form checks; the oracle needs ~1 min here.)"""
+SAME batches: 2.6 x 10^9 read k-mers, ~3.5 x 10^8 distinct, a table with a middle split level, pending record sets.
+
+  * one pass (ASCII batches, the whole table in one handle): every summary number, the whole coverage histogram and the
+    three QV counters must be identical to the oracle's;
+  * the memory-bounded mode bench.py uses at full size (the reference's map ranges, src/kreeq.cpp:59-74): the same read
+    set, resident in the 2-bit packed form, counted in THREE map-range passes into a table a third of the size -- every pass
+    rescans all reads, keeps the k-mers of its maps (key % 128), is summarised and validated against the assembly for its
+    range, then the table is cleared -- with an arena small enough to force several table passes per range: the sums over the
+    ranges must be the oracle's numbers again.
+
+(Larger scales are covered by bench.py's closed-form checks; the oracle needs ~1 min here.)"""
 import os
 
 import numpy as np
@@ -12,9 +20,11 @@ pytestmark = pytest.mark.gpu
 
 G, COV, L, K, ERR, ASM_ERR = 100_000_000, 30, 150, 21, 0.005, 1e-4
 BATCH_READS = 5_000_000
+RANGES = [(0, 43), (43, 85), (85, 128)]
 
 
-def test_configs2_shape_100mbp_vs_oracle():
+@pytest.fixture(scope="module")
+def job():
     import torch
 
     import kreeq_amd
@@ -37,29 +47,43 @@ def test_configs2_shape_100mbp_vs_oracle():
     gpu.set_option("trust_capacity", 1)
     stream = torch.cuda.Stream(dev)
     gpu.set_stream(stream.cuda_stream)
+    packed = []
     with torch.cuda.stream(stream):
         for lo in range(0, n_reads, BATCH_READS):
             n = min(BATCH_READS, n_reads - lo)
             batch = synth.reads_dev(genome, n, L, gen, err=ERR)
             gpu.count_batch_dev(batch.data_ptr(), batch.numel())          # stays pending: no read of the table in between
+            codes, inv = synth.pack_dev(batch)
+            packed.append((codes, inv, batch.numel()))
             torch.cuda.synchronize(dev)                                   # (the batch tensor is freed below)
             host = batch.cpu().numpy().tobytes()
             del batch
             cpu.count_batch(host, threads=cores)
             del host
+    sc = cpu.summary(with_hist=True)
+    c_cpu, _ = cpu.validate_sequence(assembly.cpu().numpy().tobytes(), threads=cores)
+    cpu.close()
+    return {"dev": dev, "stream": stream, "gpu": gpu, "assembly": assembly, "packed": packed, "n_reads": n_reads, "hint": hint, "sc": sc, "c_cpu": c_cpu}
+
+
+def test_configs2_shape_100mbp_vs_oracle(job):
+    import torch
+
+    from oracle import oracle as O
+
+    gpu, dev, stream, assembly, sc, c_cpu = job["gpu"], job["dev"], job["stream"], job["assembly"], job["sc"], job["c_cpu"]
+    with torch.cuda.stream(stream):
         sg = gpu.summary(with_hist=True)
         info = gpu.info()
         ctr = torch.zeros(3, dtype=torch.int64, device=dev)
         gpu.lookup_sequence_dev(assembly.data_ptr(), assembly.numel(), ctr.data_ptr())
         gpu.sync()
         c_gpu = ctr.cpu().numpy().astype(np.uint64)
-    sc = cpu.summary(with_hist=True)
-    assert sg["total"] == n_reads * (L - K + 1)
+    assert sg["total"] == job["n_reads"] * (L - K + 1)
     assert {k: v for k, v in sg.items() if k != "hist"} == {k: v for k, v in sc.items() if k != "hist"}
     assert sg["hist"] == sc["hist"]
     assert info["slots_used"] == sc["distinct"] and info["kmers_counted"] == sc["total"]
     assert info["table_passes"] <= 2, info
-    c_cpu, _ = cpu.validate_sequence(assembly.cpu().numpy().tobytes(), threads=cores)
     assert np.array_equal(c_gpu, c_cpu), (c_gpu, c_cpu)
     assert int(c_gpu[1]) == G - K + 1
     assert "%g" % O.qv(int(c_gpu[0]), int(c_gpu[1]), K) == "%g" % O.qv(int(c_cpu[0]), int(c_cpu[1]), K)
@@ -70,3 +94,43 @@ def test_configs2_shape_100mbp_vs_oracle():
         gpu.lookup_sequence_dev(assembly.data_ptr(), assembly.numel(), ctr.data_ptr())
         gpu.sync()
         assert np.array_equal(ctr.cpu().numpy().astype(np.uint64), c_cpu)
+    gpu.set_option("lookup_path", "auto")
+
+
+def test_configs2_shape_100mbp_map_range_passes_vs_oracle(job):
+    """three map-range passes over the resident packed read set, several table passes per range"""
+    import torch
+
+    import kreeq_amd
+
+    dev, stream, assembly, sc, c_cpu = job["dev"], job["stream"], job["assembly"], job["sc"], job["c_cpu"]
+    job["gpu"].close()                                                    # the one-pass table is not needed any more
+    db = kreeq_amd.KreeqDB(K, 128, capacity_hint=int(1.1 * job["hint"] / len(RANGES)))
+    db.set_option("trust_capacity", 1)
+    db.set_option("pending_bytes", 3 << 30)                               # ~7.5e8 of the ~8.7e8 records of a range: two table passes
+    db.set_stream(stream.cuda_stream)
+    tot = {"total": 0, "unique": 0, "distinct": 0, "edges": 0}
+    hist, ctr_sum, passes = {}, np.zeros(3, dtype=np.uint64), []
+    with torch.cuda.stream(stream):
+        for r, (lo, hi) in enumerate(RANGES):
+            db.set_option("count_map_range", (lo, hi))
+            before = db.info()["table_passes"]
+            for codes, inv, n in job["packed"]:
+                db.count_packed_dev(codes.data_ptr(), inv.data_ptr(), n)
+            s = db.summary(with_hist=True)
+            info = db.info()
+            passes.append(info["table_passes"] - before)
+            assert info["slots_used"] == s["distinct"] and info["kmers_counted"] == s["total"]
+            for f in tot:
+                tot[f] += s[f]
+            for c, n in s["hist"].items():
+                hist[c] = hist.get(c, 0) + n
+            ctr = torch.zeros(3, dtype=torch.int64, device=dev)
+            db.lookup_sequence_dev(assembly.data_ptr(), assembly.numel(), ctr.data_ptr(), map_lo=lo, map_hi=hi)
+            db.sync()
+            ctr_sum += ctr.cpu().numpy().astype(np.uint64)
+            db.clear()
+    assert all(p >= 2 for p in passes), passes
+    assert tot == {f: sc[f] for f in tot}, (tot, sc)
+    assert dict(sorted(hist.items())) == sc["hist"]
+    assert np.array_equal(ctr_sum, c_cpu), (ctr_sum, c_cpu)
