@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--no-third", action="store_true", help="skip the 1000 Mbp (round-2 headline) extra of a larger run")
     ap.add_argument("--pending-bytes", type=int, default=-1, help="KQ_OPT_PENDING_BYTES (-1 auto, 0 = one table pass per slice)")
     ap.add_argument("--slice-kmers", type=int, default=0, help="KQ_OPT_SLICE_KMERS (0 = the library's choice)")
+    ap.add_argument("--slice-cap", type=int, default=1 << 31, help="human workload: a batch is cut into equal slices of at most this many k-mer starts")
+    ap.add_argument("--no-overlap", action="store_true", help="KQ_OPT_OVERLAP = 0")
     ap.add_argument("--reads", type=int, default=N_READS, help="cfg1: reads per GPU (default = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="human workload: skip the configs1 / lookup / union objects")
@@ -114,7 +116,7 @@ def map_ranges(n, map_count=128):
     return [(map_count * i // n, map_count * (i + 1) // n) for i in range(n)]
 
 
-def plan_ranges(free_b, est_distinct, n_records, scratch_b, max_ranges=16):
+def plan_ranges(free_b, est_distinct, n_records, scratch_b, scratch_ranged, max_ranges=16):
     """How many map-range passes the count job is cut into on ONE GPU (the reference picks its ranges from the free memory the
     same way, src/kreeq.cpp:59-63).  A range pass rescans every read (P1 scan + hash of all k-mers, records of 1/n of them)
     into a table of 1/n of the k-mers; what is left of the HBM is the pending-record arena, and every arena-full costs one
@@ -124,7 +126,7 @@ def plan_ranges(free_b, est_distinct, n_records, scratch_b, max_ranges=16):
     best = None
     for n in range(1, max_ranges + 1):
         table = int(est_distinct / n * TABLE_MARGIN / 0.7) * 16
-        arena = free_b - table - scratch_b - (6 << 30)
+        arena = free_b - table - (scratch_b if n == 1 else scratch_ranged) - (6 << 30)
         if arena < (4 << 30):
             continue
         passes = max(1, -(-(n_records // n * 4) // arena))
@@ -180,9 +182,12 @@ def run_human(args, dev, world=1, rank=0):
     # bound; TABLE_MARGIN on top); a rank owns 1/world of the hash buckets, hence of the k-mers (5 % more room for the spread)
     est = G + n_kmers * (1.0 - (1.0 - ERR) ** k)
     starts_per_batch = (batch_reads // world) * (L + 1)
-    n_slices = max(1, -(-starts_per_batch // (1 << 31)))
+    n_slices = max(1, -(-starts_per_batch // args.slice_cap))     # two or more slices per call: their partition stages overlap (KQ_OPT_OVERLAP), a scratch set each
     slice_kmers = args.slice_kmers or (-(-starts_per_batch // n_slices) + 64)
-    scratch_b = int(10.6 * min(slice_kmers, starts_per_batch)) + (5 << 30)     # partition scratch of a slice + high-copy side table (2.7 GB at this scale) + small buffers
+    # partition scratch of a slice (two sets when the slices of a call overlap: KQ_OPT_OVERLAP, not in map-range passes) +
+    # high-copy side table (2.7 GB at this scale) + small buffers
+    scratch1 = int(10.6 * min(slice_kmers, starts_per_batch))
+    scratch_b = (2 if (n_slices > 1 or args.slice_kmers) and not args.no_overlap else 1) * scratch1 + (5 << 30)
     free_b, total_b = device_memory(dev.index)
     if sharded:
         n_ranges, passes_planned = 1, None
@@ -194,10 +199,10 @@ def run_human(args, dev, world=1, rank=0):
         if args.ranges:
             n_ranges = args.ranges
             table_b = int(est / n_ranges * TABLE_MARGIN / 0.7) * 16
-            arena_b = free_b - table_b - scratch_b - (6 << 30)
+            arena_b = free_b - table_b - (scratch_b if n_ranges == 1 else scratch1 + (5 << 30)) - (6 << 30)
             passes_planned = max(1, -(-(n_kmers // n_ranges * 4) // max(arena_b, 1)))
         else:
-            n_ranges, table_b, arena_b, passes_planned = plan_ranges(free_b, est, n_kmers, scratch_b)
+            n_ranges, table_b, arena_b, passes_planned = plan_ranges(free_b, est, n_kmers, scratch_b, scratch1 + (5 << 30))
         hint = int(TABLE_MARGIN * est / n_ranges)
         pending = args.pending_bytes if args.pending_bytes != -1 else int(arena_b)
     ranges = map_ranges(n_ranges)
@@ -218,6 +223,8 @@ def run_human(args, dev, world=1, rank=0):
     # pending-set arena: sized once, here (the library's automatic arena starts small and doubles as it fills up, so that a
     # short job never pays for tens of GB of hipMalloc); allocated by the first warm-up step, outside the timed region
     db.set_option("pending_bytes", pending)
+    if args.no_overlap:
+        db.set_option("overlap", 0)
     if args.slice_kmers or n_slices > 1:
         db.set_option("slice_kmers", slice_kmers)
 

@@ -133,8 +133,13 @@ void* kq_get_stream(kq_handle* h);
  *                          kq_insert_sharded_dev).  k-mers of other buckets are ignored by every entry point: counts drop
  *                          them, lookups do not evaluate them (their sum over the shards is the whole answer, like the map
  *                          ranges of src/kreeq.cpp:150), export / summary see the window's k-mers. */
+/*   KQ_OPT_OVERLAP        1 (default): a count call that cuts its batch into several slices (KQ_OPT_SLICE_KMERS) runs the
+ *                          partition stages of consecutive slices on two internal streams with a scratch set each (slice
+ *                          j+1's scan beside slice j's split levels) and joins them with the handle's stream before it
+ *                          returns: the caller's stream-ordered view of the handle is unchanged.  0: one stream.
+ *                          2: also in a map-range pass (KQ_OPT_COUNT_MAP_RANGE), where 1 does not fork (tests). */
 enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4, KQ_OPT_PROFILE = 5,
-       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8, KQ_OPT_PENDING_BYTES = 9, KQ_OPT_BUCKET_WINDOW = 10,
+       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8, KQ_OPT_PENDING_BYTES = 9, KQ_OPT_BUCKET_WINDOW = 10, KQ_OPT_OVERLAP = 11,
        KQ_OPT_TEST_FAIL_PLAN = 100 /* failure-path tests only: the next partition plan of a count fails with KQ_ERR_NOMEM */ };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_get_profile(kq_handle* h, char* buf, uint64_t cap);

@@ -77,6 +77,20 @@ struct kq_handle {
     bool profile = false;                // KQ_OPT_PROFILE: HIP events around the stages of the partitioned count
     std::vector<std::pair<const char*, hipEvent_t>> marks;
     void* part = nullptr; size_t part_bytes = 0;       // partitioned path: record buffers + offsets
+    // Fork / join of the slices of ONE count call (see count_seq_dev): consecutive slices run their partition stages on two
+    // internal streams with a scratch set each, so that slice j+1's P1 fills the issue slots slice j's levels leave idle.
+    // `stream` is where launches go (a fork stream while a forked slice is being enqueued), `base` the handle's stream
+    // (its own or the caller's): everything that reads the table or the device state runs there, behind a join.
+    hipStream_t base = nullptr;
+    hipStream_t fork_stream[2] = {nullptr, nullptr};
+    void* fork_part[2] = {nullptr, nullptr}; size_t fork_part_bytes[2] = {0, 0};      // [0] aliases part / part_bytes while a forked slice runs
+    bool fork_busy[2] = {false, false};              // work enqueued on the fork stream that `base` has not been joined with
+    bool fork_stale[2] = {false, false};             // a table pass was enqueued on `base` since the fork stream last waited for one
+    static constexpr int EV_RING = 64;
+    hipEvent_t ev_ring[EV_RING] = {};                // fork / join / pass events, used round-robin: an event is re-recorded only
+    uint64_t ev_next = 0;                            // after the host has seen its previous use complete (ev_get)
+    hipEvent_t ev_pass = nullptr;                    // the last table pass on `base` (forked slices write into the arena it read)
+    int overlap = 1;                                 // KQ_OPT_OVERLAP
     // pending record sets (see "pending sets" below): region-sorted records of earlier slices / batches that have not
     // been applied to the table yet; one k_count_regions pass takes them all
     void* arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
@@ -111,6 +125,29 @@ struct kq_handle {
 
 static void marks_reset(kq_handle* h);
 static int flush_pending(kq_handle* h);
+
+// ---- fork / join (count_seq_dev) ----------------------------------------------------------------------------------
+// One event per use: the ring hands out an event whose previous record has completed (the host waits for it if it has
+// not: that bounds how far the host runs ahead to EV_RING forks / joins).  Re-recording an event that a queued
+// hipStreamWaitEvent still refers to is exactly what this avoids.
+static int ev_get(kq_handle* h, hipEvent_t* out) {
+    hipEvent_t& e = h->ev_ring[h->ev_next++ % kq_handle::EV_RING];
+    if (!e) HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    else HIPC(hipEventSynchronize(e));
+    *out = e;
+    return KQ_OK;
+}
+// `base` waits for everything the fork streams have been given
+static int join_forks(kq_handle* h) {
+    for (int w = 0; w < 2; ++w) {
+        if (!h->fork_busy[w]) continue;
+        hipEvent_t e; int rc = ev_get(h, &e); if (rc) return rc;
+        HIPC(hipEventRecord(e, h->fork_stream[w]));
+        HIPC(hipStreamWaitEvent(h->base, e, 0));
+        h->fork_busy[w] = false;
+    }
+    return KQ_OK;
+}
 
 // grid-stride kernels: at most `per_cu` workgroups per CU.  8 = what is resident (kernels that flush per-workgroup
 // state at the end); the tile scanners take 32: the dispatcher balances the surplus (-4 % on k_lookup / k_count_direct)
@@ -386,7 +423,7 @@ int kq_create(kq_handle** out, int device, int k, int map_count, uint64_t capaci
     h->filt_hi = (uint32_t)map_count;
     hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(KQ_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
-    h->stream = h->own_stream;
+    h->stream = h->base = h->own_stream;
     int rc = KQ_OK;
     do {
         if (hipMalloc((void**)&h->st, sizeof(DevState)) != hipSuccess || hipHostMalloc((void**)&h->st_host, sizeof(DevState)) != hipSuccess) {
@@ -419,6 +456,10 @@ void kq_destroy(kq_handle* h) {
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->stage) (void)hipFree(h->stage);
     if (h->part) (void)hipFree(h->part);
+    for (int w = 0; w < 2; ++w) { if (h->fork_stream[w]) { (void)hipStreamSynchronize(h->fork_stream[w]); (void)hipStreamDestroy(h->fork_stream[w]); } }
+    if (h->fork_part[1]) (void)hipFree(h->fork_part[1]);
+    for (auto e : h->ev_ring) if (e) (void)hipEventDestroy(e);
+    if (h->ev_pass) (void)hipEventDestroy(h->ev_pass);
     for (int i = 0; i < kq_handle::IN_SLOTS; ++i) { if (h->in_buf[i]) (void)hipFree(h->in_buf[i]); if (h->in_consumed[i]) (void)hipEventDestroy(h->in_consumed[i]); }
     for (auto e : h->in_copied) (void)hipEventDestroy(e);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -447,7 +488,7 @@ int kq_clear(kq_handle* h) {
 int kq_set_stream(kq_handle* h, void* s) {
     if (!h) return fail(KQ_ERR_INVALID, "null handle");
     HIPC(hipStreamSynchronize(h->stream));
-    h->stream = s ? (hipStream_t)s : h->own_stream;
+    h->stream = h->base = s ? (hipStream_t)s : h->own_stream;
     return KQ_OK;
 }
 int kq_set_option(kq_handle* h, int option, int64_t value) {
@@ -473,6 +514,9 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             h->lookup_path = (int)value; return KQ_OK;
         case KQ_OPT_PROFILE: h->profile = value != 0; if (!h->profile) marks_reset(h); return KQ_OK;
         case KQ_OPT_TEST_FAIL_PLAN: h->test_fail_plan = value != 0; return KQ_OK;
+        case KQ_OPT_OVERLAP:
+            if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_OVERLAP must be 0, 1 or 2");
+            h->overlap = (int)value; return KQ_OK;
         case KQ_OPT_PENDING_BYTES: {
             if (value < -1) return fail(KQ_ERR_INVALID, "KQ_OPT_PENDING_BYTES must be -1 (auto), 0 (off) or a byte count");
             int rc = flush_pending(h);
@@ -795,7 +839,7 @@ static int arena_take(kq_handle* h, uint64_t n_max, int fmt, uint64_t R, P3Set* 
         if (budget <= h->arena_bytes && need <= h->arena_bytes) budget = 0;         // at its ceiling already
         if (budget && budget < need) return KQ_OK;
         if (budget) {
-            if (h->arena) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
+            if (h->arena) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipStreamSynchronize(h->base)); HIPC(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
             if (hipMalloc(&h->arena, budget) != hipSuccess) { (void)hipGetLastError(); h->arena = nullptr; return KQ_OK; }
             h->arena_bytes = budget; h->arena_used = 0;
         }
@@ -826,9 +870,24 @@ static int pend_add(kq_handle* h, const P3Set& set, int fmt, int aux_fmt) {
     h->pend_records += set.n_max;
     return KQ_OK;
 }
-// P3 over all pending sets
+// P3 over all pending sets.  Always on the handle's own stream (`base`), behind a join with the fork streams that wrote the
+// sets; the fork streams in turn wait for the pass before they go on (their next sets reuse the arena it reads).
+static int flush_pending_base(kq_handle* h);
 static int flush_pending(kq_handle* h) {
     if (!h->n_pend) return KQ_OK;
+    hipStream_t work = h->stream;
+    h->stream = h->base;
+    int rc = join_forks(h);
+    if (!rc) rc = flush_pending_base(h);
+    if (!rc && h->fork_stream[0]) {
+        hipEvent_t e; rc = ev_get(h, &e);
+        if (!rc && hipEventRecord(e, h->base) != hipSuccess) rc = fail(KQ_ERR_HIP, "hipEventRecord failed");
+        for (int w = 0; w < 2 && !rc; ++w) if (hipStreamWaitEvent(h->fork_stream[w], e, 0) != hipSuccess) rc = fail(KQ_ERR_HIP, "hipStreamWaitEvent failed");
+    }
+    h->stream = work;
+    return rc;
+}
+static int flush_pending_base(kq_handle* h) {
     const uint64_t R = h->n_regions;
     int rc = ensure_buf(&h->hot, &h->hot_bytes, (size_t)(R + 2) * 8);
     if (rc) return rc;
@@ -1032,7 +1091,26 @@ static int count_seq_dev(kq_handle* h, const char* d_bases, const uint16_t* d_in
             slice = std::max(slice, std::min<uint64_t>(std::min<uint64_t>(2 * h->n_slots(), 1ull << 31), by_mem));
         }
     }
-    for (uint64_t a = 0; a < kmers; a += slice) {
+    // Fork / join: with two or more slices in this call, consecutive slices alternate between two internal streams (and two
+    // scratch sets), both behind the caller's position on `base` (the input is ready there), and `base` is joined with them
+    // before the call returns -- the caller's stream-ordered view of the handle does not change, and no fork outlives a call.
+    struct ForkGuard {
+        kq_handle* h; bool swapped = false;
+        void leave() { if (swapped) { std::swap(h->part, h->fork_part[1]); std::swap(h->part_bytes, h->fork_part_bytes[1]); swapped = false; } h->stream = h->base; }
+        ~ForkGuard() { leave(); (void)join_forks(h); }
+    } guard{h};
+    // (not in a map-range pass: its slices read their record count back, and measured at full size the kernels of two such
+    // slices only time-slice the GPU -- no gain for a second scratch set taken from the arena)
+    const bool forked = h->overlap && !h->profile && h->count_path != 1 && (kmers + slice - 1) / slice >= 2 && slice >= (1u << 20) &&
+                        (h->overlap == 2 || (h->filt_lo == 0 && h->filt_hi == (uint32_t)h->map_count));
+    if (forked) {
+        for (int w = 0; w < 2; ++w) if (!h->fork_stream[w]) HIPC(hipStreamCreateWithFlags(&h->fork_stream[w], hipStreamNonBlocking));
+        hipEvent_t e_in; int erc = ev_get(h, &e_in); if (erc) return erc;
+        HIPC(hipEventRecord(e_in, h->base));
+        for (int w = 0; w < 2; ++w) HIPC(hipStreamWaitEvent(h->fork_stream[w], e_in, 0));
+    }
+    uint64_t slice_no = 0;
+    for (uint64_t a = 0; a < kmers; a += slice, ++slice_no) {
         const uint64_t b = std::min(kmers, a + slice);
         int rc = reserve(h, b - a, b - a);
         if (rc) return rc;
@@ -1061,10 +1139,19 @@ static int count_seq_dev(kq_handle* h, const char* d_bases, const uint16_t* d_in
             part = true;
         }
         if (part) {
+            if (forked) {
+                const int w = (int)(slice_no & 1);
+                if (w == 1) { std::swap(h->part, h->fork_part[1]); std::swap(h->part_bytes, h->fork_part_bytes[1]); guard.swapped = true; }
+                h->stream = h->fork_stream[w];
+                h->fork_busy[w] = true;
+            }
             rc = count_partitioned(h, ab, lead, sub_len, er, pinv);
+            if (forked) h->fork_busy[slice_no & 1] = true;            // (a table pass inside joined the stream; what followed has not been joined)
+            guard.leave();
             if (rc) return rc;
             continue;
         }
+        if (forked) { rc = join_forks(h); if (rc) return rc; }       // the direct kernel updates the table: behind everything in flight
         PartCfg filt; plan_cfg(h, &filt);
         filt.filt_lo = h->filt_lo; filt.filt_hi = h->filt_hi;
         materialize(h);
