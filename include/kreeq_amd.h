@@ -175,6 +175,8 @@ int  kq_count_batch_dev(kq_handle* h, const char* d_bases, uint64_t len);
  * has returned.  kq_count_batch_async may be called from several threads at once on one handle (the only entry point
  * that may; the calls take turns inside, none of them waits for the GPU); no other call on the handle may run concurrently
  * with them.  kq_sync() drains everything. */
+/* kq_host_free: no copy may still read the buffer -- wait for the tickets of every batch submitted from it (kq_host_wait), or
+ * kq_sync(), first; the library does not wait for them here. */
 void* kq_host_alloc(uint64_t bytes);
 void  kq_host_free(void* p);
 int  kq_count_batch_async(kq_handle* h, const char* bases, uint64_t len, uint64_t* ticket);

@@ -167,6 +167,8 @@ class ShardedCounter:
         self.force_exchange = False
         self.n_chunks = int(os.environ.get("KQ_EXCHANGE_CHUNKS", "2"))   # pipeline depth of the exchange
         self._recv = {}
+        self.check_conservation = os.environ.get("KQ_EXCHANGE_CHECK", "1") != "0"     # per batch: all-reduced records sent == received
+        self._sent = self._received = 0
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if self.world > map_count:
@@ -232,28 +234,62 @@ class ShardedCounter:
         res = engine.emit_partitioned(bases, world, slot=slot)
         return res if len(res) == 3 else (res[0], res[1], None)
 
-    def _exchange_start(self, payload, send_counts, slot=0, meta=None):
+    def _counts_begin(self, send_counts, meta, slot):
+        """enqueue the exchange of the part sizes (tiny all-to-all) and their copy to page-locked host memory; nothing waits
+        here -- the caller enqueues more GPU work (the insert of the previous chunk) before it reads them (_counts_end), so
+        that the host round trip all_to_all_single's host-side split sizes require never leaves the GPU idle"""
+        dev = meta.device if send_counts is None else None
+        if send_counts is None:
+            sc = meta.sum(dim=1)                                         # lazy emit: the part sizes are the row sums of the bucket counts, on the device
+        else:
+            dev = getattr(self.engine, "device", torch.device("cpu"))
+            sc = torch.from_numpy(send_counts).to(dev, non_blocking=True)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)                 # how many records each peer sends me
+        key = ("counts", slot)
+        host = self._recv.get(key)
+        if host is None or host.shape[1] != sc.numel():
+            host = torch.empty((2, sc.numel()), dtype=torch.int64).pin_memory() if dev.type == "cuda" else torch.empty((2, sc.numel()), dtype=torch.int64)
+            self._recv[key] = host
+        host.copy_(torch.stack([sc, rc]), non_blocking=True)
+        ev = None
+        if dev.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        return host, ev
+
+    @staticmethod
+    def _counts_end(token):
+        host, ev = token
+        if ev is not None:
+            ev.synchronize()
+        both = host.numpy()
+        return both[0].copy(), both[1].copy()
+
+    def _exchange_start(self, payload, send_counts, slot=0, meta=None, before_wait=None):
         """counts first (tiny; its result is needed on the host because all_to_all_single takes host split sizes), then
-        one asynchronous all-to-all(v) per payload array into persistent receive buffers"""
-        dev = payload[0].device
+        one asynchronous all-to-all(v) per payload array into persistent receive buffers.  `before_wait()` runs between the
+        enqueue of the count exchange and the host's read of its result."""
         if send_counts is None and self.stage_host:                      # lazy emit: the part sizes are still on the device
             send_counts = meta.sum(dim=1).cpu().numpy()
             payload = [t[:int(send_counts.sum())] for t in payload]
         if self.stage_host:
+            if before_wait is not None:
+                before_wait()
             return self._exchange_via_host(payload, send_counts, slot, meta)
-        if send_counts is None:
-            # lazy emit: send and receive counts come back in ONE host round trip
-            sc = meta.sum(dim=1)
-            rc = torch.empty_like(sc)
-            dist.all_to_all_single(rc, sc, group=self.group)
-            both = torch.stack([sc, rc]).cpu().numpy()
-            send_counts, recv_counts = both[0].copy(), both[1].copy()
-            payload = [t[:int(send_counts.sum())] for t in payload]
-        else:
-            sc = torch.from_numpy(send_counts).to(dev, non_blocking=True)
-            rc = torch.empty_like(sc)
-            dist.all_to_all_single(rc, sc, group=self.group)             # how many records each peer sends me
-            recv_counts = rc.cpu().numpy()
+        token = self._counts_begin(send_counts, meta, slot)
+        if before_wait is not None:
+            before_wait()
+        send_counts, recv_counts = self._counts_end(token)
+        payload = [t[:int(send_counts.sum())] for t in payload]
+        # conservation of the exchange (ADVICE r2): what the ranks send is what they receive
+        if self.check_conservation:
+            self._sent += int(send_counts.sum())
+            self._received += int(recv_counts.sum())
+        esz = max(t.element_size() for t in payload)
+        for c in list(send_counts) + list(recv_counts):                  # one message = one (source, destination) part of one array
+            if int(c) * esz > self.MAX_MESSAGE_BYTES:
+                raise RuntimeError(f"exchange message of {int(c)} records exceeds {self.MAX_MESSAGE_BYTES} bytes: lower KQ_EXCHANGE_MAX_BASES")
         n_recv = int(recv_counts.sum())
         received, works = [], []
         for j, t in enumerate(payload):
@@ -276,6 +312,9 @@ class ShardedCounter:
         dist.all_to_all_single(rc, sc, group=self.group)
         recv_counts = rc.numpy()
         n_recv = int(recv_counts.sum())
+        if self.check_conservation:
+            self._sent += int(send_counts.sum())
+            self._received += n_recv
         received = []
         for j, t in enumerate(payload):
             r = torch.empty(n_recv, dtype=t.dtype)
@@ -308,22 +347,32 @@ class ShardedCounter:
         # 2^28 measured 31.4 ms per 1.3e9 k-mers, 2^27 37.5, 2^29 51.2); every rank must issue the same number of
         # collectives, so the chunk count is the maximum over the ranks (one small all-reduce per batch)
         n_total, pending = 0, None
-        n_chunks = max(self.n_chunks, -(-bases.numel() // self.MAX_CHUNK_BASES))
+        rec_bytes = 4 if getattr(self.engine, "sharded5", False) else 8       # widest array of a record: u32 (+ a byte array), or u64
+        n_chunks = max(self.n_chunks, -(-bases.numel() // min(self.MAX_CHUNK_BASES, self.MAX_MESSAGE_BYTES // rec_bytes)))
         if self.world > 1:
             nc = torch.tensor([n_chunks], dtype=torch.int64, device=bases.device)
             dist.all_reduce(nc, op=dist.ReduceOp.MAX, group=self.group)
             n_chunks = int(nc.item())
         chunks = self._cut_points(bases, n_chunks)               # exactly n_chunks (possibly empty) chunks on every rank
         for i, (lo, hi) in enumerate(chunks):
-            # send buffer i % 2: the exchange of chunk i-2 was waited for before chunk i-1 was started
+            # send buffer i % 2: the exchange of chunk i-2 was waited for before chunk i-1 was started.
+            # Order of the enqueues: scan of chunk i, exchange of its part sizes, INSERT of chunk i-1 -- and only then does the
+            # host read the part sizes (the split sizes of the payload exchange): while it waits, the GPU has the scan and the
+            # insert to run, so the round trip costs no GPU time (round 2: it sat between the scan and everything else)
             payload, send_counts, meta = self._emit(self.engine, bases[lo:hi], self.world, slot=i % 2, lazy=True)
-            started = self._exchange_start(payload, send_counts, slot=i % 2, meta=meta)
-            if pending is not None:
-                self._insert_received(pending)
+            prev, pending = pending, None
+            started = self._exchange_start(payload, send_counts, slot=i % 2, meta=meta,
+                                           before_wait=(lambda p=prev: self._insert_received(p)) if prev is not None else None)
             pending = started
             n_total += started[2]
         if pending is not None:
             self._insert_received(pending)
+        if self.check_conservation and self.world > 1:
+            t = torch.tensor([self._sent, self._received], dtype=torch.int64, device=bases.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            sent, received = (int(x) for x in t.cpu())
+            if sent != received:
+                raise RuntimeError(f"record exchange lost records: {sent} sent, {received} received")
         return n_total
 
     def _insert_received(self, pending):
@@ -346,7 +395,15 @@ class ShardedCounter:
                 dist.all_reduce(ctr, op=dist.ReduceOp.SUM, group=self.group)
             return ctr.cpu().numpy().astype(np.uint64)
 
-    MAX_CHUNK_BASES = int(os.environ.get("KQ_EXCHANGE_MAX_BASES", str(1 << 28)))
+    # A chunk holds at most 2^28 bases WHATEVER the environment says, and at most 2^30 bytes of its widest record
+    # array: one (source, destination) message then stays within 1 GiB.  Round 2 saw records lost "beyond 4 GB" and never
+    # found out why.  Round 3 measured it (tools/bench_extra/a2a_4gb.py, profiles/r03/a2a_message_size.log): with this image's
+    # RCCL (2.26.6, the one torch bundles) all_to_all_single delivers a message of 1 GiB intact and only the FIRST HALF of a
+    # message of 2 GiB - 4 KiB or more (int32, uint8 and int64 alike; the rest of the receive buffer is left untouched) --
+    # a defect below this code, not in its offsets.  So _exchange_start refuses any message above MAX_MESSAGE_BYTES (the largest
+    # size verified) instead of trusting the collective, and the per-batch conservation check would catch a loss anyway.
+    MAX_CHUNK_BASES = min(1 << 28, max(1 << 16, int(os.environ.get("KQ_EXCHANGE_MAX_BASES", str(1 << 28)))))
+    MAX_MESSAGE_BYTES = 1 << 30
     HIST_DENSE = 4096        # coverages below this travel as one dense all-reduce; the few above are gathered as pairs
 
     def histogram(self):

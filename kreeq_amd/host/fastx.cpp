@@ -314,19 +314,39 @@ struct Appender {
     const BatchSink& sink;
     unsigned t;
     char* buf = nullptr;
-    size_t cap = 0, len = 0;
+    size_t cap = 0, len = 0, pool_cap = 0;
+    bool big = false;                  // buf is a one-off buffer for a sequence longer than a pool buffer
     Appender(const BatchSink& s, unsigned thread) : sink(s), t(thread) {}
     // room for a sequence of n bases (and its separator) in the current buffer, else submit it and take a fresh one
     void reserve(size_t n) {
         if (buf && len + n + 1 <= cap) return;
         flush();
+        if (pool_cap && n + 1 > pool_cap) { take_big(n); return; }
         buf = sink.acquire(t, &cap);
+        pool_cap = cap;
         len = 0;
-        if (n + 1 > cap) throw std::runtime_error("sequence of " + std::to_string(n) + " bases does not fit a " + std::to_string(cap) + "-byte read batch");
+        if (n + 1 > cap) {
+            // a sequence longer than a pool buffer (a chromosome of a FASTA given as reads): the pool buffer goes back empty
+            // and the sequence travels in a buffer of its own -- whole, so its k-mers and edges are counted exactly once
+            sink.submit(t, buf, 0);
+            buf = nullptr;
+            take_big(n);
+        }
+    }
+    void take_big(size_t n) {
+        if (!sink.acquire_big || !sink.submit_big)
+            throw std::runtime_error("sequence of " + std::to_string(n) + " bases does not fit a " + std::to_string(pool_cap) + "-byte read batch");
+        buf = sink.acquire_big(t, n + 1);
+        cap = n + 1; len = 0; big = true;
     }
     void begin() { if (len) buf[len++] = '\n'; }
     void piece(const char* a, const char* b) { memcpy(buf + len, a, (size_t)(b - a)); len += (size_t)(b - a); }
-    void flush() { if (buf && len) sink.submit(t, buf, len); buf = nullptr; len = 0; }
+    void flush() {
+        if (buf && big) sink.submit_big(t, buf, len);
+        else if (buf && len) sink.submit(t, buf, len);
+        else if (buf) sink.submit(t, buf, 0);                     // taken but never filled: back to the pool
+        buf = nullptr; len = 0; big = false;
+    }
 };
 inline const char* trim_eol(const char* a, const char* b) { while (b > a && (b[-1] == '\n' || b[-1] == '\r')) --b; return b; }
 
@@ -405,8 +425,9 @@ void read_batches_sink(const std::string& path, unsigned threads, const BatchSin
             }
             ap.flush();
         } catch (const std::exception& e) {
-            std::lock_guard<std::mutex> l(next_m);
-            if (!failed) { failed = true; first_error = e.what(); }
+            bool first = false;
+            { std::lock_guard<std::mutex> l(next_m); if (!failed) { failed = true; first = true; first_error = e.what(); } }
+            if (first && sink.abort) sink.abort();                // the other threads may be waiting for buffers this one holds
         }
     };
     std::vector<std::thread> pool;

@@ -33,10 +33,17 @@ void read_batches_parallel(const std::string& path, size_t batch_bytes, unsigned
 //   acquire(thread, &cap)     a writable buffer of cap bytes for parser thread `thread` (may block until one is free)
 //   submit(thread, buf, len)  buf holds len bytes of '\n'-separated sequences; the sink owns it again
 // Both are called concurrently from up to `threads` threads (thread ids 0..threads-1); .gz input is inflated and parsed by
-// one thread (id 0).  A single sequence must fit a buffer.
+// one thread (id 0).
+//   acquire_big(thread, n)    (optional) a one-off buffer of n bytes for a sequence that does not fit a pool buffer (a
+//                             chromosome-scale FASTA record), handed back through submit_big; without it such a sequence is an error
+//   abort()                   (optional) called once when a parser thread has failed: wakes threads blocked in acquire so that
+//                             they throw instead of waiting for buffers that will never come back
 struct BatchSink {
     std::function<char*(unsigned thread, size_t* cap)> acquire;
     std::function<void(unsigned thread, char* buf, size_t len)> submit;
+    std::function<char*(unsigned thread, size_t n)> acquire_big;
+    std::function<void(unsigned thread, char* buf, size_t len)> submit_big;
+    std::function<void()> abort;
 };
 void read_batches_sink(const std::string& path, unsigned threads, const BatchSink& sink);
 

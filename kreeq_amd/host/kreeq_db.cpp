@@ -158,6 +158,32 @@ void write_index(const std::string& db, int k, int map_count) {
     f << k << "\n" << map_count << std::endl;                       // src/kreeq-output.cpp:91
 }
 
+void read_db_hc(const std::string& db, std::vector<kq_entry>& hc_out) {
+    read_dump<Val32>(db + "/.map.hc.bin", [&](uint64_t key, const Val32& v) {
+        kq_entry e{};
+        e.key = key; e.cov = v.cov; e.hc = 1;
+        for (int w = 0; w < 4; ++w) { e.fw[w] = v.fw[w]; e.bw[w] = v.bw[w]; }
+        hc_out.push_back(e);
+    });
+}
+void read_db_maps(const std::string& db, const DbIndex& idx, int map_lo, int map_hi, const std::vector<kq_entry>& hc, std::vector<kq_entry>& out) {
+    size_t n_tomb = 0, n_hc = 0;
+    for (int m = map_lo; m < map_hi; ++m) {
+        read_dump<Val8>(db + "/.map." + std::to_string(m) + ".bin", [&](uint64_t key, const Val8& v) {
+            if (v.cov == 255) { ++n_tomb; return; }                 // lives in the high-copy map (src/graph-builder.cpp:247)
+            kq_entry e{};
+            e.key = key; e.cov = v.cov; e.hc = 0;
+            for (int w = 0; w < 4; ++w) { e.fw[w] = v.fw[w]; e.bw[w] = v.bw[w]; }
+            out.push_back(e);
+        });
+    }
+    for (auto& e : hc) {
+        const int m = (int)(e.key % (uint64_t)idx.map_count);
+        if (m >= map_lo && m < map_hi) { out.push_back(e); ++n_hc; }
+    }
+    if (n_tomb > n_hc) throw std::runtime_error("Error: int32 map missing 255 value from int8 map");   // src/kreeq.cpp:162
+}
+
 void read_db(const std::string& db, std::vector<kq_entry>& out, DbIndex* idx_out) {
     DbIndex idx = read_index(db);
     if (idx_out) *idx_out = idx;

@@ -25,6 +25,12 @@ void write_index(const std::string& db_dir, int k, int map_count);
 // Appends to `out`.
 void read_db(const std::string& db_dir, std::vector<kq_entry>& out, DbIndex* idx = nullptr);
 
+// The same in pieces, for callers that hold only a range of maps at a time (the reference's loadMapRange, src/kreeq.cpp:59-74):
+// read_db_hc reads the database's high-copy map once (it is small: the k-mers with cov >= 255); read_db_maps appends the
+// logical entries of the maps [map_lo, map_hi) -- their 8-bit maps (tombstones dropped) and the high-copy k-mers of those maps.
+void read_db_hc(const std::string& db_dir, std::vector<kq_entry>& hc_out);
+void read_db_maps(const std::string& db_dir, const DbIndex& idx, int map_lo, int map_hi, const std::vector<kq_entry>& hc, std::vector<kq_entry>& out);
+
 // Writes all map files.  `entries` = logical entries of the whole table (any order).
 void write_db(const std::string& db_dir, int k, int map_count, const std::vector<kq_entry>& entries);
 

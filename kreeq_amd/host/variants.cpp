@@ -242,14 +242,25 @@ void advance(Search& s, const Cache& cache, int k, int kmer_depth, uint32_t cov_
 
 }  // namespace
 
-std::vector<VariantSite> find_candidate_errors(kq_handle* h, int k, const std::vector<SeqRecord>& seqs, int kmer_depth, int max_span,
+GraphSource graph_of_handle(kq_handle* h) {
+    GraphSource g;
+    g.branch_scan = [h](const std::string& joined, uint32_t cov_cutoff, std::vector<uint8_t>& flags) {
+        if (kq_branch_scan(h, joined.data(), joined.size(), cov_cutoff, flags.data()) != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error());
+    };
+    g.lookup = [h](const std::vector<uint64_t>& want, std::vector<kq_entry>& got) {
+        if (kq_lookup_keys(h, want.data(), want.size(), got.data()) != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error());
+    };
+    return g;
+}
+
+std::vector<VariantSite> find_candidate_errors(const GraphSource& g, int k, const std::vector<SeqRecord>& seqs, int kmer_depth, int max_span,
                                                uint32_t cov_cutoff, const std::function<void(const std::string&)>& log) {
     // 1. device pre-filter over the whole assembly (sequences joined by a non-base byte)
     std::string joined;
     std::vector<uint64_t> offset;
     for (auto& r : seqs) { offset.push_back(joined.size()); joined += r.seq; joined.push_back('\n'); }
     std::vector<uint8_t> flags(joined.size());
-    if (kq_branch_scan(h, joined.data(), joined.size(), cov_cutoff, flags.data()) != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error());
+    g.branch_scan(joined, cov_cutoff, flags);
 
     // 2. one Search per flagged position, segment by segment (DBGtoVariants :53-169, single map range)
     std::vector<Search> searches;
@@ -317,7 +328,7 @@ std::vector<VariantSite> find_candidate_errors(kq_handle* h, int k, const std::v
             want.erase(std::unique(want.begin(), want.end()), want.end());
             if (want.empty()) throw std::runtime_error("candidate-error search stalled");
             got.resize(want.size());
-            if (kq_lookup_keys(h, want.data(), want.size(), got.data()) != KQ_OK) throw std::runtime_error(std::string("Error: ") + kq_last_error());
+            g.lookup(want, got);
             for (auto& e : got) {
                 Node n;
                 for (int w = 0; w < 4; ++w) { n.fw[w] = e.fw[w]; n.bw[w] = e.bw[w]; }

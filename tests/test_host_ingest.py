@@ -146,6 +146,10 @@ def test_sink_reader_matches(cli, tmp_path):
                 f.write(s[o:o + 60] + b"\n")
             seqs.append(s)
     assert seqsink(fa, 6, 1 << 17) == py_digest(seqs)
-    # a sequence that does not fit a buffer is refused, not truncated
-    r = subprocess.run([cli, "dbtool", "seqsink", fa, "2", "1000"], capture_output=True, text=True)
+    # a sequence that does not fit a pool buffer travels whole in a one-off buffer ...
+    assert seqsink(fa, 2, 1000) == py_digest(seqs)
+    assert seqsink(fa, 5, 257) == py_digest(seqs)
+    # ... and is refused, not truncated, by a sink that has none
+    import os
+    r = subprocess.run([cli, "dbtool", "seqsink", fa, "2", "1000"], capture_output=True, text=True, env=dict(os.environ, KQ_TEST_NO_BIG="1"))
     assert r.returncode != 0 and "does not fit" in r.stderr
