@@ -79,6 +79,12 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="cfg1 with one GPU: still run the N>1 code path (owner split -> insert)")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON: native libraries that print to file descriptor 1 (RCCL's version banner at
+    # communicator creation) are sent to stderr, the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -104,7 +110,8 @@ def main():
             dist.init_process_group(backend)
     out = run_human(args, dev, world, rank) if args.workload == "human" else run_cfg1(args, dev, world, rank, local_rank)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

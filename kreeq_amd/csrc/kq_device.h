@@ -95,7 +95,10 @@ __device__ __forceinline__ uint64_t key_of_hash(uint64_t h, uint32_t k) {
     return x ^ (x >> k);
 }
 __device__ __forceinline__ uint64_t hash_region(uint64_t h, uint64_t n_regions) { return __umulhi((uint32_t)(h >> 32), (uint32_t)n_regions); }
-__device__ __forceinline__ uint32_t hash_offset(uint64_t h, uint32_t k) { return (uint32_t)(h >> (64 - 2 * k)) & (REGION_SLOTS - 1); }
+// Home slot of a hash inside its region: the low 11 bits of the mixed value, rounded down to a QUAD of slots (16-byte aligned
+// keys in the LDS image of k_count_regions_q4: one read covers the home quad).  The probe sequence is linear from there, so
+// every kernel that probes -- table_find / table_add, the region kernels, rehash -- agrees by using this one function.
+__device__ __forceinline__ uint32_t hash_offset(uint64_t h, uint32_t k) { return (uint32_t)(h >> (64 - 2 * k)) & (REGION_SLOTS - 4); }
 // The 56 hash bits a slot stores.  k <= 28: the hash has at most 56 significant bits (left-aligned: the low 8 are
 // zero).  k >= HI_K: tables have a multiple of 256 regions, so the top 8 hash bits are region / rps.
 __device__ __forceinline__ uint64_t slot_rem(uint64_t h, uint32_t k) { return k >= HI_K ? h & REM_MASK : h >> 8; }

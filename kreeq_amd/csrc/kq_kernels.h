@@ -956,9 +956,9 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(Ta
                 const uint32_t m = cur_rec[q], aux = cur_aux[q];
                 const uint32_t low = ((m & 0xFFu) << 2) | (aux & 3u);   // the 10 hash bits below the top 32
                 const uint32_t key = TIGHT ? m >> 6 : ((top_base + (m >> 8)) << 10) | low;
-                uint32_t pos = TIGHT ? (((key + start_lo) >> off_shift) & (REGION_SLOTS - 1))          // off_shift + 11 <= 32 (k >= 11)
-                             : KC == 21 ? (((m << 2) | (aux & 3u)) & (REGION_SLOTS - 1))
-                                        : (uint32_t)(((((uint64_t)bucket << 34) | ((uint64_t)m << 2) | (aux & 3u)) >> off_shift) & (REGION_SLOTS - 1));
+                uint32_t pos = TIGHT ? (((key + start_lo) >> off_shift) & (REGION_SLOTS - 4))          // off_shift + 11 <= 32 (k >= 11); quad-aligned home (hash_offset)
+                             : KC == 21 ? (((m << 2) | (aux & 3u)) & (REGION_SLOTS - 4))
+                                        : (uint32_t)(((((uint64_t)bucket << 34) | ((uint64_t)m << 2) | (aux & 3u)) >> off_shift) & (REGION_SLOTS - 4));
                 const uint64_t pack = s_lut[TIGHT ? m & 63u : (aux >> 2) & 63u];
                 // find-or-claim: two slots of the probe sequence per LDS round trip; one CAS site
                 uint32_t slot = active ? REGION_SLOTS : 0u;             // REGION_SLOTS = still looking
@@ -1017,6 +1017,256 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(Ta
             ulonglong2 o = make_ulonglong2(0ull, 0ull);
             if ((uint32_t)a != N32_EMPTY) {
                 const uint32_t key = (uint32_t)a, cw = (uint32_t)(a >> 32), c = cw & ~N32_TOMB;
+                uint64_t cov8 = (cw & N32_TOMB) ? COV8_TOMB : c;
+                if (c > LOW_TIER_MAX) { cov8 = COV8_TOMB; hc_add(t, hash_of(key), c - LOW_TIER_MAX, 0, nullptr); }
+                o = make_ulonglong2((((uint64_t)(start_r + (key >> 10))) << 24) | ((uint64_t)(key & 1023u) << 14) | (cov8 << COV_SHIFT), s_e[i]);
+            }
+            gimg[i] = o;
+        }
+        if (tid == 0) {
+            if (s_new) atomicAdd(&t.st->slots_used, (unsigned long long)s_new);
+            if (s_kmers) atomicAdd(&t.st->kmers_added, (unsigned long long)s_kmers);
+        }
+        __syncthreads();
+    }
+}
+
+
+// ---- k_count_regions_q4: the table pass for FMT_NARROW / FMT_TIGHT records, second formulation (round 3) ------------------
+// Same job and same HBM image as k_count_regions_n32; what changes is how a wave walks its records.  n32 sent every record
+// through a divergent find-or-claim loop: a wave paid the MAXIMUM probe count of its 64 lanes (4-6 iterations of ~20
+// instructions at load 0.65) for every group of 64 records, ~100 VALU + ~110 SALU per group -- the pass was bound by that
+// instruction stream, not by LDS or HBM (round-2 VERDICT, weak #4).  Here:
+//   * a k-mer's home is a 16-byte aligned QUAD of slots (hash_offset() is quad-aligned for every kernel of the library:
+//     the probe sequence is still linear, it just starts at a multiple of four), and the LDS image keeps the 32-bit keys in
+//     an array of their own, so ONE straight-line step reads the four keys of the home quad (two 8-byte LDS reads), finds the
+//     key or the first free slot of the quad, claims it with a single CAS if need be and applies the record: no loop, no
+//     per-lane iteration count.  ~88 % of the records end there (key in its home quad, or a free slot in it);
+//   * the rest go to a small per-wave queue in LDS and are drained 64 at a time by the loop formulation -- which then runs
+//     with every lane busy on a record that needs it, instead of 64 lanes waiting for the slowest one.
+//   s_key[slot]  = key31 (the hash bits region r does not imply, as in n32) or N32_EMPTY
+//   s_cnt[slot]  = instances (bit 31 = arrived as a tombstone)
+//   s_e[slot]    = the eight u8 edge counters
+#ifndef KQ_Q4_QCAP
+#define KQ_Q4_QCAP 128
+#endif
+template <int KC, bool TIGHT>
+__global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(TableView t, const P3Set* __restrict__ sets, uint32_t n_sets, int table_is_empty,
+                                                                     unsigned long long* __restrict__ hot_list, uint32_t rps) {
+    constexpr int PF = KQ_P3_PF;
+    constexpr uint32_t GRP = 64u * PF;
+    constexpr uint32_t QCAP = KQ_Q4_QCAP, NONE = 0xFFFFFFFFu;
+    __shared__ uint64_t s_key2[REGION_SLOTS / 2];                       // the keys, read two at a time
+    __shared__ uint32_t s_cnt[REGION_SLOTS];
+    __shared__ uint64_t s_e[REGION_SLOTS];
+    __shared__ uint64_t s_lut[64];
+    __shared__ uint64_t s_q[P3_THREADS / 64][QCAP];                     // per-wave queue of records that did not resolve in their home quad: key | idx6 << 32
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_key2);
+    if (threadIdx.x < 64) s_lut[threadIdx.x] = idx6_to_pack(threadIdx.x);     // visible after the first region's barrier
+    __shared__ unsigned int s_new, s_kmers, s_grp;
+    constexpr int HC_LDS = 64;
+    __shared__ uint64_t s_hckey[HC_LDS];
+    __shared__ uint32_t s_hccnt[HC_LDS][8];
+    const int tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t k = KC ? KC : t.k;
+    const uint32_t off_shift = 42 - 2 * k;                              // k <= 21
+    for (uint64_t r = t.reg_lo + blockIdx.x; r < t.reg_hi; r += gridDim.x) {
+        SetTickets<GRP> tk;
+        tk.build(sets, n_sets, r, lane);
+        uint64_t n_recs = tk.cnt;                                       // block-uniform after the reduction
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n_recs += __shfl_xor(n_recs, o, 64);
+        ulonglong2* gimg = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
+        if (n_recs == 0) {
+            if (table_is_empty == 2)                                    // lazy kq_clear: this launch initialises every region
+                for (int i = tid; i < (int)REGION_SLOTS; i += P3_THREADS) gimg[i] = make_ulonglong2(0ull, 0ull);
+            continue;
+        }
+        if (n_recs > 32ull * REGION_SLOTS) {                            // skewed region: the folding kernel takes it
+            if (tid == 0) hot_list[1 + atomicAdd(&hot_list[0], 1ull)] = r;
+            continue;
+        }
+        const uint32_t bucket = (uint32_t)r / rps;
+        const uint32_t start_r = t.rstart[r];
+        const uint32_t top_base = (bucket << (32 - NARROW_CBITS)) - start_r;       // (top 32 hash bits of a 5-byte record) - rstart[r] = top_base + (u32 >> 8)
+        const uint32_t start_lo = start_r << 10;                                   // key + start_lo = the low 32 bits of (top 32 hash bits | the 10 below)
+        if (tid < HC_LDS) {
+            s_hckey[tid] = EMPTY_KEY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_hccnt[tid][e] = 0;
+        }
+        if (table_is_empty) {
+            for (int i = tid; i < (int)REGION_SLOTS; i += P3_THREADS) { s_key[i] = N32_EMPTY; s_cnt[i] = 0; s_e[i] = 0; }
+        } else {
+            ulonglong2 v[REGION_SLOTS / P3_THREADS];
+#pragma unroll
+            for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) v[j] = gimg[tid + j * P3_THREADS];
+#pragma unroll
+            for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) {
+                const uint64_t w0 = v[j].x;                             // rem56 | cov8 << 56, rem = hash >> 8
+                uint32_t key = N32_EMPTY, cnt = 0;
+                if (w0) {
+                    key = (((uint32_t)(w0 >> 24) - start_r) << 10) | ((uint32_t)(w0 >> 14) & 1023u);
+                    const uint32_t c = (uint32_t)(w0 >> COV_SHIFT);
+                    cnt = c == COV8_TOMB ? (N32_TOMB | LOW_TIER_MAX) : c;
+                }
+                s_key[tid + j * P3_THREADS] = key;
+                s_cnt[tid + j * P3_THREADS] = cnt;
+                s_e[tid + j * P3_THREADS] = v[j].y;
+            }
+        }
+        if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = P3_THREADS / 64; }
+        __syncthreads();
+        uint32_t n_new = 0, n_ok = 0;
+        auto hash_of = [&](uint32_t key) -> uint64_t { return ((uint64_t)(start_r + (key >> 10)) << 32) | ((uint64_t)(key & 1023u) << 22); };
+        auto add_wide = [&](uint32_t key31, uint64_t pack) {            // an edge of a k-mer beyond 254 instances: the region's LDS high-copy sums
+            const uint64_t h = hash_of(key31);
+            const uint64_t key = key_of_hash(h, t.k);
+            uint32_t e[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) e[w] = (uint32_t)(pack >> (8 * w)) & 1u;
+            int hslot = -1;
+            uint32_t hp = (uint32_t)(h >> 40) & (HC_LDS - 1);
+            for (int probe = 0; probe < HC_LDS; ++probe, hp = (hp + 1) & (HC_LDS - 1)) {
+                uint64_t cur = __hip_atomic_load(&s_hckey[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == EMPTY_KEY) cur = atomicCAS((unsigned long long*)&s_hckey[hp], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                if (cur == EMPTY_KEY || cur == key) { hslot = (int)hp; break; }
+            }
+            if (hslot >= 0) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) if (e[w]) atomicAdd(&s_hccnt[hslot][w], e[w]);
+            } else {
+                hc_add(t, h, 0, 0, e);
+            }
+        };
+        // one instance of the k-mer in `slot`
+        auto apply = [&](uint32_t slot, uint32_t key, uint64_t pack) {
+            ++n_ok;
+            const uint32_t old = atomicAdd(&s_cnt[slot], 1u);
+            if (pack) {
+                if (old < LOW_TIER_MAX) atomicAdd((unsigned long long*)&s_e[slot], (unsigned long long)pack);
+                else add_wide(key, pack);
+            }
+        };
+        // the four keys of the quad at `pos` (a multiple of four): the key's slot, or the first free one (claimed), or NONE
+        // when the quad is full of other keys (full = true) / the claim went to another key (full = false: look again)
+        auto probe_quad = [&](uint32_t pos, uint32_t key, bool& full) -> uint32_t {
+            const uint64_t q01 = __hip_atomic_load(&s_key2[pos >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint64_t q23 = __hip_atomic_load(&s_key2[(pos >> 1) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t k0 = (uint32_t)q01, k1 = (uint32_t)(q01 >> 32), k2 = (uint32_t)q23, k3 = (uint32_t)(q23 >> 32);
+            uint32_t off = k1 == key ? 1u : 4u;
+            off = k2 == key ? 2u : off;
+            off = k3 == key ? 3u : off;
+            off = k0 == key ? 0u : off;
+            full = false;
+            if (off < 4u) return pos + off;
+            uint32_t eo = k3 == N32_EMPTY ? 3u : 4u;
+            eo = k2 == N32_EMPTY ? 2u : eo;
+            eo = k1 == N32_EMPTY ? 1u : eo;
+            eo = k0 == N32_EMPTY ? 0u : eo;
+            if (eo == 4u) { full = true; return NONE; }
+            const uint32_t got = atomicCAS(&s_key[pos + eo], N32_EMPTY, key);
+            if (got == N32_EMPTY) { ++n_new; return pos + eo; }
+            return got == key ? pos + eo : NONE;
+        };
+        // home quad of a key: the low 32 bits of (top 32 hash bits | the 10 below) are key + start_lo; k < 11 (a key space
+        // of < 2^22 k-mers on a table this large: tests only) has fewer than 11 offset bits below them and takes the generic form
+        auto home_of = [&](uint32_t key) -> uint32_t {
+            return k >= 11 ? ((key + start_lo) >> off_shift) & (REGION_SLOTS - 4) : hash_offset(hash_of(key), k);
+        };
+        uint32_t qn = 0;                                                // entries in this wave's queue (wave-uniform)
+        // the queued records, 64 at a time, through the probe loop
+        auto drain = [&]() {
+            while (qn) {
+                const uint32_t n = qn < 64u ? qn : 64u;
+                qn -= n;
+                const bool act = lane < n;
+                const uint64_t ent = s_q[wave][qn + (act ? lane : 0u)];
+                const uint32_t key = (uint32_t)ent;
+                uint32_t pos = home_of(key);
+                uint32_t slot = NONE, probes = 0;
+                bool looking = act;
+                while (looking) {
+                    bool full;
+                    slot = probe_quad(pos, key, full);
+                    if (slot != NONE) looking = false;
+                    else if (full) {
+                        pos = (pos + 4) & (REGION_SLOTS - 1);
+                        if ((probes += 4) >= REGION_SLOTS) { atomicOr(&t.st->err_table_full, 1u); looking = false; }
+                    }
+                }
+                if (act && slot != NONE) apply(slot, key, s_lut[(uint32_t)(ent >> 32) & 63u]);
+            }
+        };
+        uint32_t nxt_rec[PF], nxt_aux[PF];
+        uint32_t cur_n = 0;
+        auto fetch = [&](uint32_t g, uint32_t& n) {
+            uint32_t q, off, cnt; uint64_t lo_q;
+            tk.locate(g, q, off, cnt, lo_q);
+            const uint32_t* rp = reinterpret_cast<const uint32_t*>(sets[q].recs);
+            const uint8_t* ap = sets[q].aux;
+            n = min(cnt - off, GRP);
+#pragma unroll
+            for (int qq = 0; qq < PF; ++qq) {
+                const uint64_t j = lo_q + min(off + (uint32_t)qq * 64u + lane, cnt - 1u);
+                nxt_rec[qq] = ld_global(rp + j);
+                nxt_aux[qq] = TIGHT ? 0u : ld_global(ap + j);
+            }
+        };
+        uint32_t g_cur = wave;
+        fetch(g_cur, cur_n);
+        while (g_cur < tk.n_grp) {                                      // wave-uniform
+            uint32_t cur_rec[PF], cur_aux[PF];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) { cur_rec[q] = nxt_rec[q]; cur_aux[q] = nxt_aux[q]; }
+            uint32_t g_nxt = 0;
+            if (lane == 0) g_nxt = atomicAdd(&s_grp, 1u);
+            g_nxt = __builtin_amdgcn_readfirstlane(g_nxt);
+            const uint32_t n_cur = cur_n;
+            fetch(g_nxt, cur_n);
+            g_cur = g_nxt;
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                if (qn > QCAP - 64u) drain();                            // (uniform) room for 64 more queue entries
+                const bool active = (uint32_t)q * 64u + lane < n_cur;
+                const uint32_t m = cur_rec[q], aux = cur_aux[q];
+                const uint32_t key = TIGHT ? m >> 6 : ((top_base + (m >> 8)) << 10) | ((m & 0xFFu) << 2) | (aux & 3u);
+                const uint32_t idx6 = TIGHT ? m & 63u : (aux >> 2) & 63u;
+                const uint32_t home = home_of(key);
+                const uint64_t pack = s_lut[idx6];
+                bool full;
+                uint32_t slot = NONE;
+                if (active) slot = probe_quad(home, key, full);
+                if (active && slot != NONE) apply(slot, key, pack);
+                const bool queued = active && slot == NONE;
+                const uint64_t qm = __ballot(queued);
+                if (qm) {                                                // (uniform)
+                    if (queued) s_q[wave][qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u))] = (uint64_t)key | ((uint64_t)idx6 << 32);
+                    qn += (uint32_t)__popcll((unsigned long long)qm);
+                }
+            }
+        }
+        drain();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { n_new += __shfl_down(n_new, o, 64); n_ok += __shfl_down(n_ok, o, 64); }
+        if (lane == 0) { if (n_new) atomicAdd(&s_new, n_new); if (n_ok) atomicAdd(&s_kmers, n_ok); }
+        __syncthreads();
+        if (tid < HC_LDS && s_hckey[tid] != EMPTY_KEY) {            // flush the region's high-copy sums: one entry per k-mer
+            HcSlot* hs = hc_upsert(t, s_hckey[tid]);
+            if (!hs) atomicOr(&t.st->err_hc_full, 1u);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (s_hccnt[tid][e]) atomicAdd((unsigned long long*)&hs->cnt[e], (unsigned long long)s_hccnt[tid][e]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) {
+            const int i = tid + j * P3_THREADS;
+            const uint32_t key = s_key[i];
+            ulonglong2 o = make_ulonglong2(0ull, 0ull);
+            if (key != N32_EMPTY) {
+                const uint32_t cw = s_cnt[i], c = cw & ~N32_TOMB;
                 uint64_t cov8 = (cw & N32_TOMB) ? COV8_TOMB : c;
                 if (c > LOW_TIER_MAX) { cov8 = COV8_TOMB; hc_add(t, hash_of(key), c - LOW_TIER_MAX, 0, nullptr); }
                 o = make_ulonglong2((((uint64_t)(start_r + (key >> 10))) << 24) | ((uint64_t)(key & 1023u) << 14) | (cov8 << COV_SHIFT), s_e[i]);

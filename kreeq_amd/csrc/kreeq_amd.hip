@@ -912,7 +912,11 @@ static int flush_pending_base(kq_handle* h) {
 #endif
     if (fmt == FMT_NARROW || fmt == FMT_TIGHT) {
         // ordinary regions: the compact 32-bit-key kernel; skewed ones: the generic folding kernel
+#ifdef KQ_P3_V1       // A/B build: round 2's loop formulation
 #define KQ_N32(KC, T) hipLaunchKernelGGL((k_count_regions_n32<KC, T>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps)
+#else
+#define KQ_N32(KC, T) hipLaunchKernelGGL((k_count_regions_q4<KC, T>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps)
+#endif
         if (fmt == FMT_TIGHT) { if (h->k == 21) KQ_N32(21, true); else KQ_N32(0, true); }
         else                  { if (h->k == 21) KQ_N32(21, false); else KQ_N32(0, false); }
 #undef KQ_N32
