@@ -82,14 +82,40 @@ constexpr uint64_t mul_inverse(uint64_t a) {                 // a odd: Newton it
 }
 constexpr uint64_t MIX_INV = mul_inverse(MIX_MUL);
 static_assert(MIX_MUL * MIX_INV == 1ull, "inverse");
+// k <= 24 (round 3; kreeq's default k = 21 among them): a three-round FEISTEL network on the two k-bit halves of the key, round
+// function F(R) = bits 8 .. 8+k-1 of the 24 x 24-bit product R * C.  A bijection on 2k bits like the multiply it replaces, with
+// the same occupancy statistics on k-mer sets (region counts Poisson: DESIGN.md section 3), at a third of the issue slots: the
+// 64-bit multiply is four quarter-rate 32-bit multiplies on this GPU, v_mul_u32_u24 runs at full rate -- and every count and
+// lookup kernel is bound by its instruction stream.  k >= 25 keeps the xorshift-multiply-xorshift round.
+constexpr uint32_t FEI_C0 = 0x9E3779u, FEI_C1 = 0x85EBCBu, FEI_C2 = 0xC2B2AFu;        // odd 24-bit constants
+constexpr uint32_t FEISTEL_MAX_K = 24;
+// low 32 bits of the 24 x 24-bit product (v_mul_u32_u24, full rate).  HIP declares __umul24 as returning int: a product with
+// bit 31 set would shift arithmetically -- always go through this
+__device__ __forceinline__ uint32_t umul24u(uint32_t a, uint32_t b) { return (uint32_t)__umul24(a, b); }
+__device__ __forceinline__ uint32_t fei_f(uint32_t r, uint32_t c, uint32_t k) { return (umul24u(r, c) >> 8) & ((1u << k) - 1u); }
 __device__ __forceinline__ uint64_t table_hash(uint64_t key, uint32_t k) {      // key < 4^k, 1 <= k <= 32
     const uint32_t pad = 64 - 2 * k;
+    if (k <= FEISTEL_MAX_K) {
+        uint32_t l = (uint32_t)key & ((1u << k) - 1u), r = (uint32_t)(key >> k), t;
+        t = l ^ fei_f(r, FEI_C0, k); l = r; r = t;
+        t = l ^ fei_f(r, FEI_C1, k); l = r; r = t;
+        t = l ^ fei_f(r, FEI_C2, k); l = r; r = t;
+        return (((uint64_t)l << k) | r) << pad;
+    }
     uint64_t x = key ^ (key >> k);                           // shift >= half the width: self-inverse
     x = (x * MIX_MUL) << pad;                                // left-aligned product mod 4^k
     return x ^ ((x >> k) & (~0ull << pad));
 }
 __device__ __forceinline__ uint64_t key_of_hash(uint64_t h, uint32_t k) {
     const uint32_t pad = 64 - 2 * k;
+    if (k <= FEISTEL_MAX_K) {
+        const uint64_t x = h >> pad;
+        uint32_t l = (uint32_t)(x >> k), r = (uint32_t)x & ((1u << k) - 1u), t;
+        t = r ^ fei_f(l, FEI_C2, k); r = l; l = t;          // a round maps (l, r) to (r, l ^ F(r)): undo it with (r' ^ F(l'), l')
+        t = r ^ fei_f(l, FEI_C1, k); r = l; l = t;
+        t = r ^ fei_f(l, FEI_C0, k); r = l; l = t;
+        return ((uint64_t)r << k) | l;
+    }
     uint64_t x = (h ^ ((h >> k) & (~0ull << pad))) >> pad;
     x = ((x * MIX_INV) << pad) >> pad;
     return x ^ (x >> k);

@@ -65,6 +65,7 @@ struct LevelCfg {
     // narrow levels: segment b = (bucket b >> nr_shift, sub-bucket b & (2^nr_shift - 1)) starts at region
     // bucket * nr_rps + sub * nr_sub; bin = (region - that) / nr_div (nr_inv = ceil(2^32 / nr_div))
     uint32_t nr_shift, nr_rps, nr_sub, nr_div, nr_inv;
+    uint32_t nr_mid, nr_fshift, nr_fmask, nr_f24;   // narrow_bin: middle level, 24 - sub_bits, the bits of the position inside a sub-bucket, product fits 32 bits
     // multi-GPU exchange of narrow records (receive side): spb > 1 = the input has spb segments per logical segment (one
     // run per peer rank): input segment s belongs to logical segment s / spb, whose units and output groups they share
     uint32_t spb;
@@ -77,7 +78,7 @@ __device__ __forceinline__ uint32_t level_bin(const LevelCfg& lv, uint32_t b, ui
 
 // fw/bw edge indices as src/graph-builder.cpp:98-110 assigns them
 __device__ __forceinline__ uint32_t edge_idx6(bool is_fw, uint32_t prev, uint32_t next) {
-    uint32_t f, b;
+    uint32_t f, b;                                  // (written as selects of small values: the branch-free bit form of round 3 cost k_p1_scatter 50 more spilled registers)
     if (is_fw) { f = next < 4 ? next : 7u; b = prev < 4 ? prev : 7u; }
     else       { f = prev < 4 ? 3u - prev : 7u; b = next < 4 ? 3u - next : 7u; }
     return f | (b << 3);
@@ -148,11 +149,18 @@ __device__ __forceinline__ uint32_t narrow_word_bin(uint64_t w) { return (uint32
 __device__ __forceinline__ uint32_t narrow_region(uint32_t bucket, uint32_t main32, uint64_t n_regions) {
     return __umulhi((bucket << (32 - NARROW_CBITS)) | (main32 >> NARROW_CBITS), (uint32_t)n_regions);
 }
-// bin of a narrow record (u32 part) of segment b in a narrow level
-__device__ __forceinline__ uint32_t narrow_bin(const LevelCfg& lv, uint32_t b, uint32_t main32) {
-    const uint32_t bucket = b >> lv.nr_shift, sub = b & ((1u << lv.nr_shift) - 1u);
-    const uint32_t x = narrow_region(bucket, main32, lv.n_regions) - (bucket * lv.nr_rps + sub * lv.nr_sub);
-    return lv.nr_div == 1 ? x : __umulhi(x, lv.nr_inv);             // exact: x * nr_div < 2^32
+// bin of a narrow record (u32 part) in a narrow level.  The table has 256 * rps regions and rps = 2^sb * nr_sub exactly, so
+// with f = the 24 hash bits below the bucket prefix (position inside the bucket):
+//   region - first region of the bucket = floor(f * rps / 2^24)                       (hash_region, exact because R = 256 rps)
+//   sub-bucket (middle level)           = floor(floor(f rps / 2^24) / nr_sub) = floor(f 2^sb / 2^24) = the top sb bits of f
+//   region inside its sub-bucket (last) = floor((f mod 2^(24-sb)) * nr_sub / 2^(24-sb))
+// (floor(floor(x) / n) = floor(x / n) for a positive integer n.)  A bit field for the middle level and one 24-bit multiply
+// for the last one, instead of a 32 x 32 -> high multiply for the region and a second one for the division (round 2).
+__device__ __forceinline__ uint32_t narrow_bin(const LevelCfg& lv, uint32_t /*b: the segment's first region is implied*/, uint32_t main32) {
+    const uint32_t f = main32 >> NARROW_CBITS;
+    if (lv.nr_mid) return f >> lv.nr_fshift;
+    const uint32_t fs = f & lv.nr_fmask;
+    return lv.nr_f24 ? umul24u(fs, lv.nr_sub) >> lv.nr_fshift : (uint32_t)(((uint64_t)fs * lv.nr_sub) >> lv.nr_fshift);
 }
 
 // LDS of one multisplit workgroup.  NBC = bin capacity (incl. the discard bin): 512 keeps the whole

@@ -761,6 +761,7 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
 static LevelCfg level_coarse_to_regions(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = cfg.n_coarse; lv.nb = 1u << cfg.g_shift; lv.seg_shift = cfg.g_shift; lv.out_shift = 0; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
+    lv.nr_mid = 0; lv.nr_fshift = 24; lv.nr_fmask = 0xFFFFFFu; lv.nr_f24 = 0;
     lv.spb = 1;
     return lv;
 }
@@ -775,6 +776,8 @@ static LevelCfg level_narrow(const PartCfg& cfg, uint32_t sub_bits = 0, bool mid
     if (middle) { lv.n_seg = 1u << NARROW_CBITS; lv.nb = 1u << sub_bits; lv.nr_shift = 0; lv.nr_div = subsz; }
     else        { lv.n_seg = (1u << NARROW_CBITS) << sub_bits; lv.nb = subsz; lv.nr_shift = sub_bits; lv.nr_div = 1; }
     lv.nr_inv = lv.nr_div > 1 ? (uint32_t)(((1ull << 32) + lv.nr_div - 1) / lv.nr_div) : 0;
+    lv.nr_mid = middle ? 1u : 0u; lv.nr_fshift = 24 - sub_bits; lv.nr_fmask = (1u << (24 - sub_bits)) - 1u;
+    lv.nr_f24 = ((uint64_t)subsz << (24 - sub_bits)) <= (1ull << 32) && subsz < (1u << 24) ? 1u : 0u;
     lv.spb = 1;
     return lv;
 }
@@ -792,6 +795,7 @@ static bool tight_ok(const kq_handle* h, const PartPlan& p) {
 static LevelCfg level_flat_to_coarse(const PartCfg& cfg) {
     LevelCfg lv; lv.n_regions = cfg.n_regions; lv.n_seg = 1; lv.nb = cfg.n_coarse; lv.seg_shift = 32; lv.out_shift = cfg.g_shift; lv.in_raw = 0; lv.k = 0; lv.narrow = 0; lv.top8 = 0;
     lv.nr_shift = lv.nr_rps = lv.nr_sub = lv.nr_inv = 0; lv.nr_div = 1;
+    lv.nr_mid = 0; lv.nr_fshift = 24; lv.nr_fmask = 0xFFFFFFu; lv.nr_f24 = 0;
     lv.spb = 1;
     return lv;
 }

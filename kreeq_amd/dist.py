@@ -45,18 +45,46 @@ def bucket_range(rank, world):
 
 
 _MIX_MUL = 0x9E3779B97F4A7C15
+_FEI_C = (0x9E3779, 0x85EBCB, 0xC2B2AF)
 
 
 def table_hash(keys, k):
-    """the library's table hash of canonical keys (kq_device.h: an invertible xorshift-multiply-xorshift on the 2k key bits,
-    left-aligned in 64 bits), vectorised; used by tests and by the host engine of the gloo tests"""
+    """the library's table hash of canonical keys (kq_device.h), vectorised; used by tests and by the host engine of the gloo
+    tests.  k <= 24: three Feistel rounds on the k-bit halves, F(R) = bits 8..8+k-1 of the 24 x 24-bit product R * C;
+    k >= 25: an invertible xorshift-multiply-xorshift on the 2k key bits.  Left-aligned in 64 bits either way."""
     keys = np.asarray(keys, dtype=np.uint64)
     pad = np.uint64(64 - 2 * k)
+    if k <= 24:
+        m = np.uint64((1 << k) - 1)
+        lo, hi = keys & m, keys >> np.uint64(k)
+        for c in _FEI_C:
+            t = lo ^ ((((hi * np.uint64(c)) & np.uint64(0xFFFFFFFF)) >> np.uint64(8)) & m)
+            lo, hi = hi, t
+        return ((lo << np.uint64(k)) | hi) << pad
     x = keys ^ (keys >> np.uint64(k))
     with np.errstate(over="ignore"):
         x = (x * np.uint64(_MIX_MUL)) << pad
     hi_mask = np.uint64((~0 << (64 - 2 * k)) & 0xFFFFFFFFFFFFFFFF)
     return x ^ ((x >> np.uint64(k)) & hi_mask)
+
+
+def key_of_hash(h, k):
+    """inverse of table_hash (kq_device.h key_of_hash): the canonical key of a left-aligned 64-bit table hash"""
+    h = np.asarray(h, dtype=np.uint64)
+    pad = np.uint64(64 - 2 * k)
+    if k <= 24:
+        m = np.uint64((1 << k) - 1)
+        x = h >> pad
+        lo, hi = x >> np.uint64(k), x & m
+        for c in reversed(_FEI_C):
+            t = hi ^ ((((lo * np.uint64(c)) & np.uint64(0xFFFFFFFF)) >> np.uint64(8)) & m)
+            hi, lo = lo, t
+        return (hi << np.uint64(k)) | lo
+    inv = np.uint64(pow(_MIX_MUL, -1, 1 << 64))
+    with np.errstate(over="ignore"):
+        x = (h ^ ((h >> np.uint64(k)) & (~np.uint64(0) << pad))) >> pad
+        x = ((x * inv) << pad) >> pad
+    return x ^ (x >> np.uint64(k))
 
 
 def bucket_of(keys, k):

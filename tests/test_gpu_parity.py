@@ -360,14 +360,8 @@ def _unpack_records(recs, k):
     """packed 8-byte records (include/kreeq_amd.h: kq_emit_packed_dev) -> (key, reference edge byte)"""
     recs = recs.astype(np.uint64)
     # bits 0..55 = top 56 bits of the left-aligned invertible mix of the key (kq_device.h table_hash): undo it
-    u = np.uint64
-    inv = u(pow(0x9E3779B97F4A7C15, -1, 1 << 64))
-    pad, kk = u(64 - 2 * k), u(k)
-    h = recs << u(8)
-    with np.errstate(over="ignore"):
-        x = (h ^ ((h >> kk) & (~u(0) << pad))) >> pad
-        x = ((x * inv) << pad) >> pad
-    key = x ^ (x >> kk)
+    from kreeq_amd.dist import key_of_hash
+    key = key_of_hash(recs << np.uint64(8), k)
     f = ((recs >> np.uint64(56)) & np.uint64(7)).astype(np.int64)
     b = ((recs >> np.uint64(59)) & np.uint64(7)).astype(np.int64)
     edge = np.where(f < 4, 1 << (7 - np.minimum(f, 3)), 0) | np.where(b < 4, 1 << (7 - (4 + np.minimum(b, 3))), 0)
