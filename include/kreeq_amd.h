@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KQ_ABI_VERSION 3
+#define KQ_ABI_VERSION 4
 
 typedef enum {
     KQ_OK = 0,

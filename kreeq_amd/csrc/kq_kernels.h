@@ -1050,10 +1050,13 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(Ta
 #ifndef KQ_Q4_QCAP
 #define KQ_Q4_QCAP 128
 #endif
+#ifndef KQ_Q4_PF_TIGHT
+#define KQ_Q4_PF_TIGHT 4       // records per lane and ticket for 4-byte records (one register each): 1000 Mbp 20.2 -> 18.7 ms per step against 2; 5-byte records keep 2 (35 spilled registers at 4, no gain)
+#endif
 template <int KC, bool TIGHT>
 __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(TableView t, const P3Set* __restrict__ sets, uint32_t n_sets, int table_is_empty,
                                                                      unsigned long long* __restrict__ hot_list, uint32_t rps) {
-    constexpr int PF = KQ_P3_PF;
+    constexpr int PF = TIGHT ? KQ_Q4_PF_TIGHT : KQ_P3_PF;
     constexpr uint32_t GRP = 64u * PF;
     constexpr uint32_t QCAP = KQ_Q4_QCAP, NONE = 0xFFFFFFFFu;
     __shared__ uint64_t s_key2[REGION_SLOTS / 2];                       // the keys, read two at a time

@@ -25,7 +25,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.kq_abi_version() == 3       # 3: bucket ownership of kq_emit_sharded_dev, windows, packed input
+    assert lib.kq_abi_version() == 4       # 4: KQ_OPT_OVERLAP, quad-aligned slot homes and the Feistel table hash (opaque record formats changed)
 
 
 def test_no_cpu_fallback(lib):
