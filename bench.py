@@ -44,6 +44,7 @@ BYTES_PER_LOOKUP = 18        # 1 B base + 17 B entry read
 BYTES_PER_UNION = 51         # 17 B read x 2 + 17 B write
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 TABLE_MARGIN = 1.04          # table capacity hint over the expected distinct k-mers (the table is sized hint / 0.7 slots)
+TABLE_LOAD = 0.8             # load factor the human workload's table is sized for: expected distinct k-mers / slots (0.67 -> 0.8: -3 % at 3 Gbp; 0.85 another -4 %, but a region then overflows at 7 sigma)
 CPU_SAMPLE_READS = 5_000_000 # reads of the cpu_baseline sample
 
 
@@ -68,6 +69,7 @@ def main():
     ap.add_argument("--slice-kmers", type=int, default=0, help="KQ_OPT_SLICE_KMERS (0 = the library's choice)")
     ap.add_argument("--slice-cap", type=int, default=1 << 31, help="human workload: a batch is cut into equal slices of at most this many k-mer starts")
     ap.add_argument("--no-overlap", action="store_true", help="KQ_OPT_OVERLAP = 0")
+    ap.add_argument("--table-load", type=float, default=TABLE_LOAD, help="human workload: load factor the table is sized for (expected distinct k-mers / slots)")
     ap.add_argument("--reads", type=int, default=N_READS, help="cfg1: reads per GPU (default = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="human workload: skip the configs1 / lookup / union objects")
@@ -123,7 +125,7 @@ def map_ranges(n, map_count=128):
     return [(map_count * i // n, map_count * (i + 1) // n) for i in range(n)]
 
 
-def plan_ranges(free_b, est_distinct, n_records, scratch_b, scratch_ranged, max_ranges=16):
+def plan_ranges(free_b, est_distinct, n_records, scratch_b, scratch_ranged, margin=TABLE_MARGIN, max_ranges=16):
     """How many map-range passes the count job is cut into on ONE GPU (the reference picks its ranges from the free memory the
     same way, src/kreeq.cpp:59-63).  A range pass rescans every read (P1 scan + hash of all k-mers, records of 1/n of them)
     into a table of 1/n of the k-mers; what is left of the HBM is the pending-record arena, and every arena-full costs one
@@ -132,7 +134,7 @@ def plan_ranges(free_b, est_distinct, n_records, scratch_b, scratch_ranged, max_
     -> (n_ranges, table_bytes, arena_bytes, table_passes_per_range)"""
     best = None
     for n in range(1, max_ranges + 1):
-        table = int(est_distinct / n * TABLE_MARGIN / 0.7) * 16
+        table = int(est_distinct / n * margin / 0.7) * 16
         arena = free_b - table - (scratch_b if n == 1 else scratch_ranged) - (6 << 30)
         if arena < (4 << 30):
             continue
@@ -188,6 +190,7 @@ def run_human(args, dev, world=1, rank=0):
     # distinct k-mers: the genome's + one novel k-mer per read window with at least one substitution (jellyfish -s style
     # bound; TABLE_MARGIN on top); a rank owns 1/world of the hash buckets, hence of the k-mers (5 % more room for the spread)
     est = G + n_kmers * (1.0 - (1.0 - ERR) ** k)
+    margin = 0.7 / args.table_load                    # the library sizes the table capacity_hint / 0.7 slots
     starts_per_batch = (batch_reads // world) * (L + 1)
     n_slices = max(1, -(-starts_per_batch // args.slice_cap))     # two or more slices per call: their partition stages overlap (KQ_OPT_OVERLAP), a scratch set each
     slice_kmers = args.slice_kmers or (-(-starts_per_batch // n_slices) + 64)
@@ -198,19 +201,19 @@ def run_human(args, dev, world=1, rank=0):
     free_b, total_b = device_memory(dev.index)
     if sharded:
         n_ranges, passes_planned = 1, None
-        hint = int(TABLE_MARGIN * est) if world == 1 else int(1.05 * TABLE_MARGIN * est / world)
+        hint = int(margin * est) if world == 1 else int(1.05 * margin * est / world)
         pending = args.pending_bytes
         if pending == -1:
             pending = int(max(1 << 30, free_b - hint / 0.7 * 16 - scratch_b - (8 << 30) - (2 * starts_per_batch * 6 if world > 1 else 0)))
     else:
         if args.ranges:
             n_ranges = args.ranges
-            table_b = int(est / n_ranges * TABLE_MARGIN / 0.7) * 16
+            table_b = int(est / n_ranges * margin / 0.7) * 16
             arena_b = free_b - table_b - (scratch_b if n_ranges == 1 else scratch1 + (5 << 30)) - (6 << 30)
             passes_planned = max(1, -(-(n_kmers // n_ranges * 4) // max(arena_b, 1)))
         else:
-            n_ranges, table_b, arena_b, passes_planned = plan_ranges(free_b, est, n_kmers, scratch_b, scratch1 + (5 << 30))
-        hint = int(TABLE_MARGIN * est / n_ranges)
+            n_ranges, table_b, arena_b, passes_planned = plan_ranges(free_b, est, n_kmers, scratch_b, scratch1 + (5 << 30), margin)
+        hint = int(margin * est / n_ranges)
         pending = args.pending_bytes if args.pending_bytes != -1 else int(arena_b)
     ranges = map_ranges(n_ranges)
 
