@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--slice-kmers", type=int, default=0, help="KQ_OPT_SLICE_KMERS (0 = the library's choice)")
     ap.add_argument("--slice-cap", type=int, default=1 << 31, help="human workload: a batch is cut into equal slices of at most this many k-mer starts")
     ap.add_argument("--no-overlap", action="store_true", help="KQ_OPT_OVERLAP = 0")
+    ap.add_argument("--no-map-pass-cache", action="store_true", help="map-range passes: every pass runs its own histogram scan (KQ_OPT_COUNT_MAP_PASSES off)")
     ap.add_argument("--table-load", type=float, default=TABLE_LOAD, help="human workload: load factor the table is sized for (expected distinct k-mers / slots)")
     ap.add_argument("--reads", type=int, default=N_READS, help="cfg1: reads per GPU (default = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -254,10 +255,16 @@ def run_human(args, dev, world=1, rank=0):
 
     if n_ranges > 1:
         db.set_option("count_map_range", ranges[0])
+        if n_ranges in (2, 4, 8) and not args.no_map_pass_cache:
+            # the batches are resident and unchanged for the whole job: the first range pass counts every slice for all ranges,
+            # the later ones skip the histogram scan (KQ_OPT_COUNT_MAP_PASSES)
+            db.set_option("count_map_passes", n_ranges)
     for i in range(warmup):              # sizes the scratch and the pending-set arena, warms the code objects
         count(i)
     db.sync()
     db.clear()
+    if n_ranges in (2, 4, 8) and not sharded and not args.no_map_pass_cache:
+        db.set_option("count_map_passes", n_ranges)      # drops the count matrices the warm-up made: the timed job makes its own
     barrier()
 
     # The timed region: the K batches go through the count hot path once per map range (each pass ends with everything applied:

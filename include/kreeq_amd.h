@@ -138,8 +138,13 @@ void* kq_get_stream(kq_handle* h);
  *                          j+1's scan beside slice j's split levels) and joins them with the handle's stream before it
  *                          returns: the caller's stream-ordered view of the handle is unchanged.  0: one stream.
  *                          2: also in a map-range pass (KQ_OPT_COUNT_MAP_RANGE), where 1 does not fork (tests). */
+/*   KQ_OPT_COUNT_MAP_PASSES n = 2, 4 or 8 (1 = off): the caller counts the SAME RESIDENT batches once per range of the equal split of
+ *                          the maps into n (KQ_OPT_COUNT_MAP_RANGE = [r mapCount / n, (r + 1) mapCount / n), any order) and vouches
+ *                          that a batch keeps its device address and content between those passes.  The first pass that scans a
+ *                          slice then counts its k-mers for all n ranges in one histogram scan and keeps the count matrices (<= 4 GB);
+ *                          the other passes skip that scan.  Results never depend on it.  Setting the option drops what is kept. */
 enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4, KQ_OPT_PROFILE = 5,
-       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8, KQ_OPT_PENDING_BYTES = 9, KQ_OPT_BUCKET_WINDOW = 10, KQ_OPT_OVERLAP = 11,
+       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8, KQ_OPT_PENDING_BYTES = 9, KQ_OPT_BUCKET_WINDOW = 10, KQ_OPT_OVERLAP = 11, KQ_OPT_COUNT_MAP_PASSES = 12,
        KQ_OPT_TEST_FAIL_PLAN = 100 /* failure-path tests only: the next partition plan of a count fails with KQ_ERR_NOMEM */ };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_get_profile(kq_handle* h, char* buf, uint64_t cap);

@@ -139,6 +139,9 @@ template <int BINMODE>
 __device__ __forceinline__ uint32_t p1_bin_of(const PartCfg& cfg, uint64_t key, uint64_t h) {
     // 4: hash-prefix bucket behind the map-range filter of a memory-bounded pass (KQ_OPT_COUNT_MAP_RANGE; map_count a power
     // of two): one subtract + compare decides, rejected k-mers go to the discard bin
+    // 5 (histogram only): the hash-prefix bucket of EVERY k-mer, filed under the map range it belongs to (n_rng equal ranges of a
+    // power-of-two map count): one scan of a resident batch yields the count matrices of all its map-range passes
+    if (BINMODE == 5) return (((((uint32_t)key & cfg.map_mask) * cfg.n_rng) >> __popc(cfg.map_mask)) << NARROW_CBITS) | (uint32_t)(h >> (64 - NARROW_CBITS));
     if (BINMODE == 4) return (((uint32_t)key & cfg.map_mask) - cfg.filt_lo < cfg.filt_hi - cfg.filt_lo) ? (uint32_t)(h >> (64 - NARROW_CBITS)) : cfg.n_coarse;
     return BINMODE == 3 ? ((((((uint32_t)key & cfg.map_mask) * (cfg.n_coarse >> cfg.owner_sub)) >> __popc(cfg.map_mask)) << cfg.owner_sub) |
                           (threadIdx.x & ((1u << cfg.owner_sub) - 1u)))         // owner rank x lane sub-bin; map_count a power of two, no filter

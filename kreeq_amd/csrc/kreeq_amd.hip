@@ -91,6 +91,13 @@ struct kq_handle {
     uint64_t ev_next = 0;                            // after the host has seen its previous use complete (ev_get)
     hipEvent_t ev_pass = nullptr;                    // the last table pass on `base` (forked slices write into the arena it read)
     int overlap = 1;                                 // KQ_OPT_OVERLAP
+    // KQ_OPT_COUNT_MAP_PASSES: count matrices of resident batches, made for all map ranges by the first pass that scans a slice
+    struct HistKey { const void* ab; const void* pinv; uint64_t lead, len, er_lo, er_hi; uint32_t g1, n_rng; int k;
+                     bool operator==(const HistKey& o) const { return ab == o.ab && pinv == o.pinv && lead == o.lead && len == o.len && er_lo == o.er_lo && er_hi == o.er_hi && g1 == o.g1 && n_rng == o.n_rng && k == o.k; } };
+    struct HistEntry { HistKey key; unsigned long long* m1_all; size_t bytes; };
+    std::vector<HistEntry> hist_cache;
+    size_t hist_cache_bytes = 0;
+    int map_passes = 1;
     // pending record sets (see "pending sets" below): region-sorted records of earlier slices / batches that have not
     // been applied to the table yet; one k_count_regions pass takes them all
     void* arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
@@ -456,6 +463,7 @@ void kq_destroy(kq_handle* h) {
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->stage) (void)hipFree(h->stage);
     if (h->part) (void)hipFree(h->part);
+    for (auto& e : h->hist_cache) (void)hipFree(e.m1_all);
     for (int w = 0; w < 2; ++w) { if (h->fork_stream[w]) { (void)hipStreamSynchronize(h->fork_stream[w]); (void)hipStreamDestroy(h->fork_stream[w]); } }
     if (h->fork_part[1]) (void)hipFree(h->fork_part[1]);
     for (auto e : h->ev_ring) if (e) (void)hipEventDestroy(e);
@@ -514,6 +522,14 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             h->lookup_path = (int)value; return KQ_OK;
         case KQ_OPT_PROFILE: h->profile = value != 0; if (!h->profile) marks_reset(h); return KQ_OK;
         case KQ_OPT_TEST_FAIL_PLAN: h->test_fail_plan = value != 0; return KQ_OK;
+        case KQ_OPT_COUNT_MAP_PASSES: {
+            if (value != 1 && value != 2 && value != 4 && value != 8) return fail(KQ_ERR_INVALID, "KQ_OPT_COUNT_MAP_PASSES must be 1, 2, 4 or 8");
+            if ((h->map_count & (h->map_count - 1)) != 0 || value > h->map_count) return fail(KQ_ERR_INVALID, "KQ_OPT_COUNT_MAP_PASSES needs a power-of-two map count");
+            HIPC(hipStreamSynchronize(h->stream));
+            for (auto& e : h->hist_cache) (void)hipFree(e.m1_all);
+            h->hist_cache.clear(); h->hist_cache_bytes = 0;
+            h->map_passes = (int)value; return KQ_OK;
+        }
         case KQ_OPT_OVERLAP:
             if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_OVERLAP must be 0, 1 or 2");
             h->overlap = (int)value; return KQ_OK;
@@ -608,7 +624,7 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false
     cfg->raw_out = 0;
     // 5-byte records (FMT_NARROW): first split on the top 8 hash bits, which needs every bucket to own a
     // whole number of regions (kq_create rounds large tables to a multiple of 256 regions; doubling keeps it)
-    cfg->narrow = 0; cfg->sub_bits = 0; cfg->owner_sub = 0;
+    cfg->narrow = 0; cfg->sub_bits = 0; cfg->owner_sub = 0; cfg->n_rng = 0;
     if (allow_narrow && (h->k <= (int)NARROW_MAX_K || h->k > PART_MAX_K) && cfg->n_regions >= (uint64_t)NB_MAX && cfg->n_regions % (1u << NARROW_CBITS) == 0) {
         const uint64_t rps = cfg->n_regions >> NARROW_CBITS;
         // one level bucket -> regions while a bucket has < mid_rps regions (the multisplit writes runs of 4096 / fan-out
@@ -694,8 +710,39 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     const bool owner_plain = cfg.mode == 1 && cfg.map_mask != 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;   // multi-GPU owner split
     const bool narrow_filt = cfg.mode == 0 && cfg.narrow && !plain && cfg.map_mask != 0 && h->k <= (int)NARROW_MAX_K;   // map-range pass on a bucketed table
     const int binmode = owner_plain ? 3 : narrow_filt ? 4 : !plain ? 0 : cfg.narrow ? 2 : 1;
+    // KQ_OPT_COUNT_MAP_PASSES = n: this map-range pass is one of n over RESIDENT batches (the caller vouches that a batch keeps
+    // its address and content between the passes).  The first pass that scans a slice counts for all n ranges in one histogram
+    // launch (bin = range * 256 + bucket: the block of a range is contiguous in the bin-major matrix) and keeps the raw counts;
+    // every pass takes its block from there -- (n - 1) of the n histogram scans of a slice are never run.
+    bool have_hist = false;
+    if (narrow_filt && h->map_passes > 1 && P1_F == 1) {
+        const uint32_t n = (uint32_t)h->map_passes, per = cfg.map_count / n, rr = cfg.filt_lo / per;
+        if (cfg.filt_lo == rr * per && cfg.filt_hi == (rr + 1) * per) {
+            const kq_handle::HistKey key{ab, pinv, lead, len, er.lo, er.hi, p->g1, n, h->k};
+            const size_t block = (size_t)(1u << NARROW_CBITS) * p->g1 * sizeof(unsigned long long);
+            kq_handle::HistEntry* ent = nullptr;
+            for (auto& e : h->hist_cache) if (e.key == key) { ent = &e; break; }
+            if (!ent && h->hist_cache_bytes + n * block <= ((size_t)4 << 30)) {
+                unsigned long long* buf = nullptr;
+                if (hipMalloc((void**)&buf, n * block) == hipSuccess) {
+                    PartCfg all = cfg;
+                    all.n_rng = n; all.n_coarse = n << NARROW_CBITS;
+                    if (h->k == 21) hipLaunchKernelGGL((k_p1_hist<5, 21>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, all, er, p->g1, buf, pinv);
+                    else hipLaunchKernelGGL((k_p1_hist<5, 0>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, all, er, p->g1, buf, pinv);
+                    h->hist_cache.push_back(kq_handle::HistEntry{key, buf, n * block});
+                    h->hist_cache_bytes += n * block;
+                    ent = &h->hist_cache.back();
+                } else (void)hipGetLastError();
+            }
+            if (ent) {
+                (void)hipMemcpyAsync(p->m1, (const char*)ent->m1_all + rr * block, block, hipMemcpyDeviceToDevice, h->stream);
+                have_hist = true;
+            }
+        }
+    }
 #define KQ_P1H(B, K) hipLaunchKernelGGL((k_p1_hist<B, K>), dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1, pinv)
-    if (binmode == 2) { if (h->k == 21) KQ_P1H(2, 21); else KQ_P1H(2, 0); }
+    if (have_hist) { }
+    else if (binmode == 2) { if (h->k == 21) KQ_P1H(2, 21); else KQ_P1H(2, 0); }
     else if (binmode == 1) { if (h->k == 31) KQ_P1H(1, 31); else KQ_P1H(1, 0); }
     else if (binmode == 3) { if (h->k == 21) KQ_P1H(3, 21); else KQ_P1H(3, 0); }
     else if (binmode == 4) { if (h->k == 21) KQ_P1H(4, 21); else KQ_P1H(4, 0); }

@@ -210,3 +210,41 @@ def test_small_batches_behind_a_large_pending_job(kq, O):
     one = O.OracleDB(k, 128)
     one.count_batch(big, threads=8)
     assert H.entries_equal(gpu.export(), one.export())
+
+
+@pytest.mark.parametrize("n,hint", [(2, 5_000_000), (4, 100_000_000)])
+def test_map_pass_count_matrices_are_reused(kq, O, n, hint):
+    """KQ_OPT_COUNT_MAP_PASSES: resident batches counted once per range of the equal split of the maps; the first pass that scans
+    a slice counts for all ranges, the others take their count matrix from there.  Every range's table equals the oracle's
+    k-mers of those maps -- in any order of the ranges, for sliced batches, and again after a clear (matrices reused)."""
+    import torch
+
+    k = 21
+    raw = [H.synth_reads(30_000, 150, 500_000, seed=40 + i, err=0.006, n_rate=0.001)[0] for i in range(2)]
+    dev = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in raw]
+    ref = O.OracleDB(k, 128)
+    for b in raw:
+        ref.count_batch(b, threads=8)
+    want = ref.export()
+    maps = want["key"] % np.uint64(128)
+    gpu = kq.KreeqDB(k, 128, capacity_hint=hint)
+    gpu.set_option("trust_capacity", 1)
+    gpu.set_option("count_path", "partitioned")
+    gpu.set_option("slice_kmers", 1_700_000)          # three slices per batch
+    gpu.set_option("count_map_passes", n)
+    per = 128 // n
+    for cycle in range(2):
+        order = list(range(n)) if cycle == 0 else list(reversed(range(n)))
+        for r in order:
+            gpu.clear()
+            gpu.set_option("count_map_range", (r * per, (r + 1) * per))
+            for t in dev:
+                gpu.count_batch_dev(t.data_ptr(), t.numel())
+            got = gpu.export()
+            assert H.entries_equal(got, want[(maps >= r * per) & (maps < (r + 1) * per)]), (cycle, r)
+    # a range that is not one of the n: counted the ordinary way
+    gpu.clear()
+    gpu.set_option("count_map_range", (5, 77))
+    for t in dev:
+        gpu.count_batch_dev(t.data_ptr(), t.numel())
+    assert H.entries_equal(gpu.export(), want[(maps >= 5) & (maps < 77)])
