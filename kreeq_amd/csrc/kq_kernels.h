@@ -1053,6 +1053,12 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(Ta
 #ifndef KQ_Q4_QCAP
 #define KQ_Q4_QCAP 128
 #endif
+#ifndef KQ_Q4_DEPTH
+#define KQ_Q4_DEPTH 1          // tickets a wave has in flight, 4-byte records: 2 was measured (38 spilled registers): 3 Gbp 74.8 -> 85.1 ms per step, with two records per lane 78.8
+#endif
+#ifndef KQ_Q4_DEPTH_NT
+#define KQ_Q4_DEPTH_NT 1       // 5-byte records (small tables: few sets, long pieces)
+#endif
 #ifndef KQ_Q4_PF_TIGHT
 #define KQ_Q4_PF_TIGHT 4       // records per lane and ticket for 4-byte records (one register each): 1000 Mbp 20.2 -> 18.7 ms per step against 2; 5-byte records keep 2 (35 spilled registers at 4, no gain)
 #endif
@@ -1060,6 +1066,7 @@ template <int KC, bool TIGHT>
 __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(TableView t, const P3Set* __restrict__ sets, uint32_t n_sets, int table_is_empty,
                                                                      unsigned long long* __restrict__ hot_list, uint32_t rps) {
     constexpr int PF = TIGHT ? KQ_Q4_PF_TIGHT : KQ_P3_PF;
+    constexpr int DEPTH = TIGHT ? KQ_Q4_DEPTH : KQ_Q4_DEPTH_NT;            // tickets a wave has in flight
     constexpr uint32_t GRP = 64u * PF;
     constexpr uint32_t QCAP = KQ_Q4_QCAP, NONE = 0xFFFFFFFFu;
     __shared__ uint64_t s_key2[REGION_SLOTS / 2];                       // the keys, read two at a time
@@ -1096,9 +1103,12 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
         // the first records of this wave are requested NOW: their latency (an HBM round trip behind the ticket build's two)
         // runs under the image set-up and the barrier instead of behind them (round 3: a region visit is mostly such
         // dependent round trips -- 23 ns per region and pass at 5.3 M regions whatever the number of records)
-        uint32_t nxt_rec[PF], nxt_aux[PF];
-        uint32_t cur_n = 0;
-        auto fetch = [&](uint32_t g, uint32_t& n) {
+        // (DEPTH = 2 keeps two tickets per wave in flight: a region's records come as one short piece per pending set, ~170
+        // records of each of 30 sets at 3 Gbp, every piece from another place of the arena.  Measured and not the default.)
+        constexpr int NW = P3_THREADS / 64;
+        uint32_t recA[PF], auxA[PF], recB[PF], auxB[PF];
+        uint32_t nA = 0, nB = 0;
+        auto fetch = [&](uint32_t g, uint32_t (&rec)[PF], uint32_t (&aux)[PF], uint32_t& n) {
             uint32_t q, off, cnt; uint64_t lo_q;
             tk.locate(g, q, off, cnt, lo_q);
             const uint32_t* rp = reinterpret_cast<const uint32_t*>(sets[q].recs);
@@ -1107,12 +1117,13 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
 #pragma unroll
             for (int qq = 0; qq < PF; ++qq) {
                 const uint64_t j = lo_q + min(off + (uint32_t)qq * 64u + lane, cnt - 1u);
-                nxt_rec[qq] = ld_global(rp + j);
-                nxt_aux[qq] = TIGHT ? 0u : ld_global(ap + j);
+                rec[qq] = ld_global(rp + j);
+                aux[qq] = TIGHT ? 0u : ld_global(ap + j);
             }
         };
-        uint32_t g_cur = wave;
-        fetch(g_cur, cur_n);
+        uint32_t gA = wave, gB = wave + NW;                              // the first two tickets of a wave are its own; the rest come from s_grp
+        fetch(gA, recA, auxA, nA);
+        if (DEPTH == 2) fetch(gB, recB, auxB, nB);
         const uint32_t bucket = (uint32_t)r / rps;
         const uint32_t start_r = t.rstart[r];
         const uint32_t top_base = (bucket << (32 - NARROW_CBITS)) - start_r;       // (top 32 hash bits of a 5-byte record) - rstart[r] = top_base + (u32 >> 8)
@@ -1142,7 +1153,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
                 s_e[tid + j * P3_THREADS] = v[j].y;
             }
         }
-        if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = P3_THREADS / 64; }
+        if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = DEPTH * (P3_THREADS / 64); }
         __syncthreads();
         uint32_t n_new = 0, n_ok = 0;
         auto hash_of = [&](uint32_t key) -> uint64_t { return ((uint64_t)(start_r + (key >> 10)) << 32) | ((uint64_t)(key & 1023u) << 22); };
@@ -1225,16 +1236,13 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
                 if (act && slot != NONE) apply(slot, key, s_lut[(uint32_t)(ent >> 32) & 63u]);
             }
         };
-        while (g_cur < tk.n_grp) {                                      // wave-uniform
-            uint32_t cur_rec[PF], cur_aux[PF];
-#pragma unroll
-            for (int q = 0; q < PF; ++q) { cur_rec[q] = nxt_rec[q]; cur_aux[q] = nxt_aux[q]; }
-            uint32_t g_nxt = 0;
-            if (lane == 0) g_nxt = atomicAdd(&s_grp, 1u);
-            g_nxt = __builtin_amdgcn_readfirstlane(g_nxt);
-            const uint32_t n_cur = cur_n;
-            fetch(g_nxt, cur_n);
-            g_cur = g_nxt;
+        auto grab = [&]() -> uint32_t {
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(&s_grp, 1u);
+            return __builtin_amdgcn_readfirstlane(g);
+        };
+        // the PF x 64 records of one ticket
+        auto process = [&](const uint32_t (&cur_rec)[PF], const uint32_t (&cur_aux)[PF], uint32_t n_cur) {
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 if (qn > QCAP - 64u) drain();                            // (uniform) room for 64 more queue entries
@@ -1254,6 +1262,29 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
                     if (queued) s_q[wave][qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u))] = (uint64_t)key | ((uint64_t)idx6 << 32);
                     qn += (uint32_t)__popcll((unsigned long long)qm);
                 }
+            }
+        };
+        // tickets are handed out in increasing order and a wave looks at A, B, A, B ...: the first ticket past the end ends its walk
+        for (;;) {                                                      // wave-uniform
+            if (gA >= tk.n_grp) break;
+            {
+                uint32_t cur_rec[PF], cur_aux[PF];
+#pragma unroll
+                for (int q = 0; q < PF; ++q) { cur_rec[q] = recA[q]; cur_aux[q] = auxA[q]; }
+                const uint32_t n_cur = nA;
+                gA = grab();
+                fetch(gA, recA, auxA, nA);
+                process(cur_rec, cur_aux, n_cur);
+            }
+            if (DEPTH == 2) {
+                if (gB >= tk.n_grp) break;
+                uint32_t cur_rec[PF], cur_aux[PF];
+#pragma unroll
+                for (int q = 0; q < PF; ++q) { cur_rec[q] = recB[q]; cur_aux[q] = auxB[q]; }
+                const uint32_t n_cur = nB;
+                gB = grab();
+                fetch(gB, recB, auxB, nB);
+                process(cur_rec, cur_aux, n_cur);
             }
         }
         drain();
