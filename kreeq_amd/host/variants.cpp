@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <deque>
 #include <stdexcept>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <unordered_set>
@@ -322,7 +323,25 @@ std::vector<VariantSite> find_candidate_errors(const GraphSource& g, int k, cons
         for (;;) {
             want.clear();
             bool any = false;
-            for (size_t i = lo; i < hi; ++i) if (!searches[i].done) { advance(searches[i], cache, k, kmer_depth, cov_cutoff, want); any = any || !searches[i].done; }
+            // the searches of a round are independent (each reads the cache and its own state): a few host threads share
+            // them when there are enough (HiFi-scale inputs flag tens of thousands of positions per batch)
+            const size_t n_live = hi - lo;
+            unsigned n_thr = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+            if (n_live < 512) n_thr = 1;
+            if (n_thr > 1) {
+                std::vector<std::vector<uint64_t>> wants(n_thr);
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < n_thr; ++t)
+                    pool.emplace_back([&, t] {
+                        const size_t a = lo + n_live * t / n_thr, b = lo + n_live * (t + 1) / n_thr;
+                        for (size_t i = a; i < b; ++i) if (!searches[i].done) advance(searches[i], cache, k, kmer_depth, cov_cutoff, wants[t]);
+                    });
+                for (auto& th : pool) th.join();
+                for (auto& w : wants) want.insert(want.end(), w.begin(), w.end());
+            } else {
+                for (size_t i = lo; i < hi; ++i) if (!searches[i].done) advance(searches[i], cache, k, kmer_depth, cov_cutoff, want);
+            }
+            for (size_t i = lo; i < hi && !any; ++i) any = !searches[i].done;
             if (!any) break;
             std::sort(want.begin(), want.end());
             want.erase(std::unique(want.begin(), want.end()), want.end());
