@@ -1084,6 +1084,9 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t k = KC ? KC : t.k;
     const uint32_t off_shift = 42 - 2 * k;                              // k <= 21
+#ifdef KQ_STAMPS
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     for (uint64_t r = t.reg_lo + blockIdx.x; r < t.reg_hi; r += gridDim.x) {
         SetTickets<GRP> tk;
         tk.build(sets, n_sets, r, lane);
@@ -1121,6 +1124,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
                 aux[qq] = TIGHT ? 0u : ld_global(ap + j);
             }
         };
+        KQ_STAMP(0);                                                    // kernel start -> ticket build + reduction done
         uint32_t gA = wave, gB = wave + NW;                              // the first two tickets of a wave are its own; the rest come from s_grp
         fetch(gA, recA, auxA, nA);
         if (DEPTH == 2) fetch(gB, recB, auxB, nB);
@@ -1155,6 +1159,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
         }
         if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = DEPTH * (P3_THREADS / 64); }
         __syncthreads();
+        KQ_STAMP(1);                                                    // first fetch issued, image init / load, barrier
         uint32_t n_new = 0, n_ok = 0;
         auto hash_of = [&](uint32_t key) -> uint64_t { return ((uint64_t)(start_r + (key >> 10)) << 32) | ((uint64_t)(key & 1023u) << 22); };
         auto add_wide = [&](uint32_t key31, uint64_t pack) {            // an edge of a k-mer beyond 254 instances: the region's LDS high-copy sums
@@ -1288,6 +1293,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
             }
         }
         drain();
+        KQ_STAMP(2);                                                    // record walk (wave 0)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { n_new += __shfl_down(n_new, o, 64); n_ok += __shfl_down(n_ok, o, 64); }
         if (lane == 0) { if (n_new) atomicAdd(&s_new, n_new); if (n_ok) atomicAdd(&s_kmers, n_ok); }
@@ -1313,6 +1319,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
             }
             gimg[i] = o;
         }
+        KQ_STAMP(3);                                                    // barrier (slowest wave), high-copy flush, image store (waited for)
         if (tid == 0) {
             if (s_new) atomicAdd(&t.st->slots_used, (unsigned long long)s_new);
             if (s_kmers) atomicAdd(&t.st->kmers_added, (unsigned long long)s_kmers);

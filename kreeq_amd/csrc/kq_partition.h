@@ -297,7 +297,13 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
         const uint32_t j = tid + it * THREADS;
         if (j < total) {
             if (FMT == FMT_NARROW) {
+#ifdef KQ_EXP_NOSTORE      // timing experiment only (results are wrong): how much of a scatter's time its global stores are
+                if (KQ_EXP_NOSTORE >= 2) continue;
+#endif
                 reinterpret_cast<uint32_t*>(out)[cg[it]] = (uint32_t)cv[it];
+#ifdef KQ_EXP_NOSTORE
+                continue;
+#endif
                 if (out_aux) out_aux[cg[it]] = (uint8_t)(cv[it] >> 48);       // (uniform) FMT_TIGHT output has no lockstep byte
             } else {
                 out[cg[it]] = cv[it];
