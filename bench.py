@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--slice-kmers", type=int, default=0, help="KQ_OPT_SLICE_KMERS (0 = the library's choice)")
     ap.add_argument("--slice-cap", type=int, default=1 << 31, help="human workload: a batch is cut into equal slices of at most this many k-mer starts")
     ap.add_argument("--no-overlap", action="store_true", help="KQ_OPT_OVERLAP = 0")
+    ap.add_argument("--narrow-mid", type=int, default=0, help="KQ_OPT_NARROW_MID (tuning: regions per bucket from which the record split gets a middle level)")
     ap.add_argument("--no-map-pass-cache", action="store_true", help="map-range passes: every pass runs its own histogram scan (KQ_OPT_COUNT_MAP_PASSES off)")
     ap.add_argument("--table-load", type=float, default=TABLE_LOAD, help="human workload: load factor the table is sized for (expected distinct k-mers / slots)")
     ap.add_argument("--reads", type=int, default=N_READS, help="cfg1: reads per GPU (default = BASELINE configs[1])")
@@ -236,6 +237,8 @@ def run_human(args, dev, world=1, rank=0):
     db.set_option("pending_bytes", pending)
     if args.no_overlap:
         db.set_option("overlap", 0)
+    if args.narrow_mid:
+        db.set_option("narrow_mid", args.narrow_mid)
     if args.slice_kmers or n_slices > 1:
         db.set_option("slice_kmers", slice_kmers)
 
