@@ -1250,6 +1250,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
         auto process = [&](const uint32_t (&cur_rec)[PF], const uint32_t (&cur_aux)[PF], uint32_t n_cur) {
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
+                if ((uint32_t)q * 64u >= n_cur) break;                   // (uniform) a ticket is one piece of one set: often shorter than PF x 64 records
                 if (qn > QCAP - 64u) drain();                            // (uniform) room for 64 more queue entries
                 const bool active = (uint32_t)q * 64u + lane < n_cur;
                 const uint32_t m = cur_rec[q], aux = cur_aux[q];
