@@ -97,17 +97,22 @@ def test_configs2_shape_100mbp_vs_oracle(job):
     gpu.set_option("lookup_path", "auto")
 
 
-def test_configs2_shape_100mbp_map_range_passes_vs_oracle(job):
-    """three map-range passes over the resident packed read set, several table passes per range"""
+@pytest.mark.parametrize("ranges,shared_hist", [(RANGES, False), ([(0, 64), (64, 128)], True)])
+def test_configs2_shape_100mbp_map_range_passes_vs_oracle(job, ranges, shared_hist):
+    """map-range passes over the resident packed read set, several table passes per range: three uneven ranges, and bench.py's
+    own configuration -- two equal ranges with one histogram scan for both (KQ_OPT_COUNT_MAP_PASSES)"""
     import torch
 
     import kreeq_amd
 
+    RANGES = ranges
     dev, stream, assembly, sc, c_cpu = job["dev"], job["stream"], job["assembly"], job["sc"], job["c_cpu"]
     job["gpu"].close()                                                    # the one-pass table is not needed any more
     db = kreeq_amd.KreeqDB(K, 128, capacity_hint=int(1.1 * job["hint"] / len(RANGES)))
     db.set_option("trust_capacity", 1)
-    db.set_option("pending_bytes", 3 << 30)                               # ~7.5e8 of the ~8.7e8 records of a range: two table passes
+    db.set_option("pending_bytes", (3 << 30) * 3 // len(RANGES))          # most, not all, of the records of a range: two table passes
+    if shared_hist:
+        db.set_option("count_map_passes", len(RANGES))
     db.set_stream(stream.cuda_stream)
     tot = {"total": 0, "unique": 0, "distinct": 0, "edges": 0}
     hist, ctr_sum, passes = {}, np.zeros(3, dtype=np.uint64), []
