@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--slice-kmers", type=int, default=0, help="KQ_OPT_SLICE_KMERS (0 = the library's choice)")
     ap.add_argument("--slice-cap", type=int, default=1 << 31, help="human workload: a batch is cut into equal slices of at most this many k-mer starts")
     ap.add_argument("--no-overlap", action="store_true", help="KQ_OPT_OVERLAP = 0")
+    ap.add_argument("--range-by", choices=["map", "bucket"], default="map",
+                    help="human workload in several passes: ranges of the reference's maps (key %% 128) or of the table's 256 hash-prefix buckets")
     ap.add_argument("--narrow-mid", type=int, default=0, help="KQ_OPT_NARROW_MID (tuning: regions per bucket from which the record split gets a middle level)")
     ap.add_argument("--no-map-pass-cache", action="store_true", help="map-range passes: every pass runs its own histogram scan (KQ_OPT_COUNT_MAP_PASSES off)")
     ap.add_argument("--table-load", type=float, default=TABLE_LOAD, help="human workload: load factor the table is sized for (expected distinct k-mers / slots)")
@@ -217,7 +219,8 @@ def run_human(args, dev, world=1, rank=0):
             n_ranges, table_b, arena_b, passes_planned = plan_ranges(free_b, est, n_kmers, scratch_b, scratch1 + (5 << 30), margin)
         hint = int(margin * est / n_ranges)
         pending = args.pending_bytes if args.pending_bytes != -1 else int(arena_b)
-    ranges = map_ranges(n_ranges)
+    by_bucket = args.range_by == "bucket" and n_ranges > 1 and not sharded
+    ranges = map_ranges(n_ranges, 256) if by_bucket else map_ranges(n_ranges)
 
     counter = None
     if sharded:
@@ -256,8 +259,14 @@ def run_human(args, dev, world=1, rank=0):
         else:
             db.count_batch_dev(t.data_ptr(), t.numel())
 
+    def set_range(rg):
+        if by_bucket:
+            db.set_option("bucket_window", rg[0] | (rg[1] << 16))
+        else:
+            db.set_option("count_map_range", rg)
+
     if n_ranges > 1:
-        db.set_option("count_map_range", ranges[0])
+        set_range(ranges[0])
         if n_ranges in (2, 4, 8) and not args.no_map_pass_cache:
             # the batches are resident and unchanged for the whole job: the first range pass counts every slice for all ranges,
             # the later ones skip the histogram scan (KQ_OPT_COUNT_MAP_PASSES)
@@ -280,7 +289,7 @@ def run_human(args, dev, world=1, rank=0):
     info = None
     for r, (mlo, mhi) in enumerate(ranges):
         if n_ranges > 1:
-            db.set_option("count_map_range", (mlo, mhi))
+            set_range((mlo, mhi))
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -307,7 +316,10 @@ def run_human(args, dev, world=1, rank=0):
             c_r = counter.validate(assembly).tolist()
         else:
             ctr = torch.zeros(3, dtype=torch.int64, device=dev)
-            db.lookup_sequence_dev(assembly.data_ptr(), assembly.numel(), ctr.data_ptr(), map_lo=mlo, map_hi=mhi)
+            if by_bucket:                # the window answers for the k-mers of its buckets only
+                db.lookup_sequence_dev(assembly.data_ptr(), assembly.numel(), ctr.data_ptr())
+            else:
+                db.lookup_sequence_dev(assembly.data_ptr(), assembly.numel(), ctr.data_ptr(), map_lo=mlo, map_hi=mhi)
             torch.cuda.synchronize(dev)
             c_r = ctr.cpu().tolist()
         t_val += time.perf_counter() - tv

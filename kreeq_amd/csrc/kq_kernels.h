@@ -142,6 +142,8 @@ __device__ __forceinline__ uint32_t p1_bin_of(const PartCfg& cfg, uint64_t key, 
     // 5 (histogram only): the hash-prefix bucket of EVERY k-mer, filed under the map range it belongs to (n_rng equal ranges of a
     // power-of-two map count): one scan of a resident batch yields the count matrices of all its map-range passes
     if (BINMODE == 5) return (((((uint32_t)key & cfg.map_mask) * cfg.n_rng) >> __popc(cfg.map_mask)) << NARROW_CBITS) | (uint32_t)(h >> (64 - NARROW_CBITS));
+    // 6: hash-prefix bucket, k-mers outside the table's bucket window dropped (a shard / a bucket-range pass holds only its own buckets)
+    if (BINMODE == 6) { const uint32_t b = (uint32_t)(h >> (64 - NARROW_CBITS)); return b - cfg.win_lo < cfg.win_hi - cfg.win_lo ? b : cfg.n_coarse; }
     if (BINMODE == 4) return (((uint32_t)key & cfg.map_mask) - cfg.filt_lo < cfg.filt_hi - cfg.filt_lo) ? (uint32_t)(h >> (64 - NARROW_CBITS)) : cfg.n_coarse;
     return BINMODE == 3 ? ((((((uint32_t)key & cfg.map_mask) * (cfg.n_coarse >> cfg.owner_sub)) >> __popc(cfg.map_mask)) << cfg.owner_sub) |
                           (threadIdx.x & ((1u << cfg.owner_sub) - 1u)))         // owner rank x lane sub-bin; map_count a power of two, no filter
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_p1_hist(const uint8_t* __restr
             if (valid) {
                 const uint64_t key = fw < rv ? fw : rv;
                 const uint32_t b = p1_bin_of<BINMODE>(cfg, key, table_hash(key, (uint32_t)k));
-                if ((BINMODE != 0 && BINMODE != 4) || b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
+                if ((BINMODE != 0 && BINMODE != 4 && BINMODE != 6) || b < cfg.n_coarse) atomicAdd(&s_hist[b], 1u);
             }
         });
         __syncthreads();

@@ -43,6 +43,7 @@ struct PartCfg {
                           // bins serialises its LDS rank atomics on a few addresses); the parts stay contiguous.  The histogram
                           // and the scatter pass give a k-mer the same lane, hence the same sub-bin
     uint32_t sub_bits;    // narrow: > 0 = a middle level cuts each bucket into 2^sub_bits sub-buckets first (very large tables)
+    uint32_t win_lo, win_hi;   // bin mode 6: the table is a window of the hash-prefix buckets [win_lo, win_hi): k-mers of other buckets are dropped in P1
     uint32_t n_rng;       // k_p1_hist bin mode 5 (KQ_OPT_COUNT_MAP_PASSES): count for all n_rng equal map ranges at once, bin = range * 256 + bucket
 };
 

@@ -390,6 +390,13 @@ static int set_window(kq_handle* h, uint32_t lo, uint32_t hi) {
     if (lo >= hi || hi > 256) return fail(KQ_ERR_INVALID, "bucket window [%u, %u) is not a range of the 256 hash-prefix buckets", lo, hi);
     if (h->k > (int)NARROW_MAX_K) return fail(KQ_ERR_INVALID, "bucket windows need k <= %u (5-byte records)", NARROW_MAX_K);
     if (!h->table_empty || h->n_pend || h->kmers_bound) return fail(KQ_ERR_INVALID, "the bucket window is chosen before anything is counted");
+    // an empty windowed table moves to another window of the same width without a new allocation (bucket-range passes of one
+    // GPU: count the buckets [0, 128), clear, count [128, 256) into the same memory)
+    if (h->windowed && hi - lo == h->win_hi - h->win_lo && !(lo == 0 && hi == 256)) {
+        HIPC(hipStreamSynchronize(h->stream));
+        h->win_lo = lo; h->win_hi = hi;
+        return KQ_OK;
+    }
     const uint64_t nb = hi - lo;
     const uint64_t alloc_now = h->n_alloc_regions();
     uint64_t virt = round_regions(std::max<uint64_t>((alloc_now + nb - 1) / nb * 256, (uint64_t)NB_MAX), h->k);
@@ -624,7 +631,7 @@ static void plan_cfg(const kq_handle* h, PartCfg* cfg, bool allow_narrow = false
     cfg->raw_out = 0;
     // 5-byte records (FMT_NARROW): first split on the top 8 hash bits, which needs every bucket to own a
     // whole number of regions (kq_create rounds large tables to a multiple of 256 regions; doubling keeps it)
-    cfg->narrow = 0; cfg->sub_bits = 0; cfg->owner_sub = 0; cfg->n_rng = 0;
+    cfg->narrow = 0; cfg->sub_bits = 0; cfg->owner_sub = 0; cfg->n_rng = 0; cfg->win_lo = 0; cfg->win_hi = 1u << NARROW_CBITS;
     if (allow_narrow && (h->k <= (int)NARROW_MAX_K || h->k > PART_MAX_K) && cfg->n_regions >= (uint64_t)NB_MAX && cfg->n_regions % (1u << NARROW_CBITS) == 0) {
         const uint64_t rps = cfg->n_regions >> NARROW_CBITS;
         // one level bucket -> regions while a bucket has < mid_rps regions (the multisplit writes runs of 4096 / fan-out
@@ -709,7 +716,8 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     const bool plain = cfg.mode == 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;
     const bool owner_plain = cfg.mode == 1 && cfg.map_mask != 0 && cfg.filt_lo == 0 && cfg.filt_hi == cfg.map_count;   // multi-GPU owner split
     const bool narrow_filt = cfg.mode == 0 && cfg.narrow && !plain && cfg.map_mask != 0 && h->k <= (int)NARROW_MAX_K;   // map-range pass on a bucketed table
-    const int binmode = owner_plain ? 3 : narrow_filt ? 4 : !plain ? 0 : cfg.narrow ? 2 : 1;
+    const bool narrow_win = plain && cfg.narrow && h->k <= (int)NARROW_MAX_K && (cfg.win_lo != 0 || cfg.win_hi != (1u << NARROW_CBITS));   // windowed table: own buckets only
+    const int binmode = owner_plain ? 3 : narrow_filt ? 4 : narrow_win ? 6 : !plain ? 0 : cfg.narrow ? 2 : 1;
     // KQ_OPT_COUNT_MAP_PASSES = n: this map-range pass is one of n over RESIDENT batches (the caller vouches that a batch keeps
     // its address and content between the passes).  The first pass that scans a slice counts for all n ranges in one histogram
     // launch (bin = range * 256 + bucket: the block of a range is contiguous in the bin-major matrix) and keeps the raw counts;
@@ -740,8 +748,35 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
             }
         }
     }
+    // the same for bucket-range passes (windowed table): the unfiltered bucket matrix serves every window -- the rows of the
+    // other buckets are zeroed before the scan
+    if (narrow_win && h->map_passes > 1 && P1_F == 1) {
+        const kq_handle::HistKey key{ab, pinv, lead, len, er.lo, er.hi, p->g1, 0xB0C4E7u, h->k};
+        const size_t block = (size_t)(1u << NARROW_CBITS) * p->g1 * sizeof(unsigned long long), row = (size_t)p->g1 * sizeof(unsigned long long);
+        kq_handle::HistEntry* ent = nullptr;
+        for (auto& e : h->hist_cache) if (e.key == key) { ent = &e; break; }
+        if (!ent && h->hist_cache_bytes + block <= ((size_t)4 << 30)) {
+            unsigned long long* buf = nullptr;
+            if (hipMalloc((void**)&buf, block) == hipSuccess) {
+                PartCfg all = cfg;
+                all.win_lo = 0; all.win_hi = 1u << NARROW_CBITS;
+                if (h->k == 21) hipLaunchKernelGGL((k_p1_hist<2, 21>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, all, er, p->g1, buf, pinv);
+                else hipLaunchKernelGGL((k_p1_hist<2, 0>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, all, er, p->g1, buf, pinv);
+                h->hist_cache.push_back(kq_handle::HistEntry{key, buf, block});
+                h->hist_cache_bytes += block;
+                ent = &h->hist_cache.back();
+            } else (void)hipGetLastError();
+        }
+        if (ent) {
+            (void)hipMemcpyAsync(p->m1, ent->m1_all, block, hipMemcpyDeviceToDevice, h->stream);
+            if (cfg.win_lo) (void)hipMemsetAsync(p->m1, 0, (size_t)cfg.win_lo * row, h->stream);
+            if (cfg.win_hi < (1u << NARROW_CBITS)) (void)hipMemsetAsync((char*)p->m1 + (size_t)cfg.win_hi * row, 0, (size_t)((1u << NARROW_CBITS) - cfg.win_hi) * row, h->stream);
+            have_hist = true;
+        }
+    }
 #define KQ_P1H(B, K) hipLaunchKernelGGL((k_p1_hist<B, K>), dim3(p->g1 * P1_F), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->g1, p->m1, pinv)
     if (have_hist) { }
+    else if (binmode == 6) { if (h->k == 21) KQ_P1H(6, 21); else KQ_P1H(6, 0); }
     else if (binmode == 2) { if (h->k == 21) KQ_P1H(2, 21); else KQ_P1H(2, 0); }
     else if (binmode == 1) { if (h->k == 31) KQ_P1H(1, 31); else KQ_P1H(1, 0); }
     else if (binmode == 3) { if (h->k == 21) KQ_P1H(3, 21); else KQ_P1H(3, 0); }
@@ -755,6 +790,7 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
 #define KQ_P1S(W, N, B, K) hipLaunchKernelGGL((k_p1_scatter<W, N, B, K>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt, pinv)
     if (cfg.narrow && h->k > PART_MAX_K) { if (plain && h->k == 31) KQ_P1S(FMT_TOP8, 512, 2, 31); else if (plain) KQ_P1S(FMT_TOP8, 512, 2, 0); else KQ_P1S(FMT_TOP8, 512, 0, 0); }
     else if (narrow_filt)  { if (h->k == 21) KQ_P1S(FMT_NARROW, 512, 4, 21); else KQ_P1S(FMT_NARROW, 512, 4, 0); }
+    else if (narrow_win)   { if (h->k == 21) KQ_P1S(FMT_NARROW, 512, 6, 21); else KQ_P1S(FMT_NARROW, 512, 6, 0); }
     else if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1S(FMT_NARROW, 512, 2, 21); else if (plain) KQ_P1S(FMT_NARROW, 512, 2, 0); else KQ_P1S(FMT_NARROW, 512, 0, 0); }     // 256 buckets
     else if (out_aux && plain && h->k == 31) { if (small) KQ_P1S(FMT_WIDE, 512, 1, 31); else KQ_P1S(FMT_WIDE, NB_MAX, 1, 31); }   // the HiFi k
     else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512, 0, 0); else KQ_P1S(FMT_WIDE, NB_MAX, 0, 0); }
@@ -1037,6 +1073,7 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     uint8_t* a1 = has_aux ? p.aux1 : nullptr;
     uint8_t* a2 = has_aux ? p.aux2 : nullptr;
     p.cfg.filt_lo = h->filt_lo; p.cfg.filt_hi = h->filt_hi;      // KQ_OPT_COUNT_MAP_RANGE
+    if (h->windowed) { p.cfg.win_lo = h->win_lo; p.cfg.win_hi = h->win_hi; }      // a window drops foreign buckets in P1
     const bool leveled = p.fmt == FMT_NARROW || p.fmt == FMT_TOP8 || p.two_level;
     P3Set set; bool in_arena = false;
     const bool tight = tight_ok(h, p);
@@ -1044,7 +1081,7 @@ static int count_partitioned(kq_handle* h, const uint8_t* ab, uint64_t lead, uin
     // A map-range pass (KQ_OPT_COUNT_MAP_RANGE: the reference's memory-bounded mode, src/kreeq.cpp:59-74) keeps a fraction of
     // the k-mers it scans: its pending set is sized by the record count P1 found, not by the starts of the slice, so that the
     // arena holds as many RECORDS per table pass as it would without the filter (one small read-back per slice)
-    const bool filtered = p.cfg.filt_lo != 0 || p.cfg.filt_hi != p.cfg.map_count;
+    const bool filtered = p.cfg.filt_lo != 0 || p.cfg.filt_hi != p.cfg.map_count || h->windowed;      // (a window keeps its own buckets only)
     if (leveled && !filtered) { rc = arena_take(h, p.n_max, set_fmt, p.R, &set, &in_arena); if (rc) return rc; }
     marks_reset(h);
     mark(h, "start");
@@ -1157,7 +1194,7 @@ static int count_seq_dev(kq_handle* h, const char* d_bases, const uint16_t* d_in
     // (not in a map-range pass: its slices read their record count back, and measured at full size the kernels of two such
     // slices only time-slice the GPU -- no gain for a second scratch set taken from the arena)
     const bool forked = h->overlap && !h->profile && h->count_path != 1 && (kmers + slice - 1) / slice >= 2 && slice >= (1u << 20) &&
-                        (h->overlap == 2 || (h->filt_lo == 0 && h->filt_hi == (uint32_t)h->map_count));
+                        (h->overlap == 2 || (h->filt_lo == 0 && h->filt_hi == (uint32_t)h->map_count && !h->windowed));
     if (forked) {
         for (int w = 0; w < 2; ++w) if (!h->fork_stream[w]) HIPC(hipStreamCreateWithFlags(&h->fork_stream[w], hipStreamNonBlocking));
         hipEvent_t e_in; int erc = ev_get(h, &e_in); if (erc) return erc;

@@ -248,3 +248,42 @@ def test_map_pass_count_matrices_are_reused(kq, O, n, hint):
     for t in dev:
         gpu.count_batch_dev(t.data_ptr(), t.numel())
     assert H.entries_equal(gpu.export(), want[(maps >= 5) & (maps < 77)])
+
+
+@pytest.mark.parametrize("n,hint,passes_opt", [(2, 3_000_000, 2), (4, 60_000_000, 4), (2, 3_000_000, 1)])
+def test_bucket_range_passes(kq, O, n, hint, passes_opt):
+    """memory-bounded counting by ranges of the 256 hash-prefix buckets on ONE GPU: the table is the window of a range
+    (KQ_OPT_BUCKET_WINDOW), k-mers of other buckets are dropped in P1, the window moves to the next range without a new
+    allocation after a clear; the union of the ranges' tables is the oracle's table, their QV counters add up -- with and
+    without the shared count matrix (KQ_OPT_COUNT_MAP_PASSES), in both range orders"""
+    import torch
+
+    k = 21
+    raw = [H.synth_reads(30_000, 150, 500_000, seed=60 + i, err=0.006, n_rate=0.001)[0] for i in range(2)]
+    _, genome = H.synth_reads(10, 150, 500_000, seed=60)
+    dev = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in raw]
+    ref = O.OracleDB(k, 128)
+    for b in raw:
+        ref.count_batch(b, threads=8)
+    want = ref.export()
+    c_want, _ = ref.validate_sequence(genome)
+    gpu = kq.KreeqDB(k, 128, capacity_hint=hint)
+    gpu.set_option("trust_capacity", 1)
+    gpu.set_option("count_path", "partitioned")
+    gpu.set_option("slice_kmers", 1_700_000)
+    gpu.set_option("count_map_passes", passes_opt)
+    per = 256 // n
+    for cycle in range(2):
+        parts, ctr = [], np.zeros(3, dtype=np.uint64)
+        for r in (range(n) if cycle == 0 else reversed(range(n))):
+            gpu.clear()
+            gpu.set_option("bucket_window", (r * per) | (((r + 1) * per) << 16))
+            for t in dev:
+                gpu.count_batch_dev(t.data_ptr(), t.numel())
+            parts.append(gpu.export())
+            c, _ = gpu.lookup_sequence(genome)
+            ctr += c
+        got = np.concatenate(parts)
+        got = got[np.argsort(got["key"])]
+        assert H.entries_equal(got, want), cycle
+        assert np.array_equal(ctr, c_want)
