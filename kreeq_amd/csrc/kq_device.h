@@ -365,9 +365,10 @@ __device__ __forceinline__ void convert16(const uint4& v, bool all_in, int64_t g
 // PACKED input (pinv != nullptr; kq_pack_bases, include/kreeq_amd.h): `ab` is the array of 2-bit codes, one u32 per 16 bases
 // (base i at bits 2i), pinv the array of invalid-base masks, one u16 per 16 bases -- the scanner's own LDS format, 6 bytes
 // per 16 bases over PCIe instead of 16; the lane's unit comes back in v.x / v.y and tile_store skips the conversion.
+// (`lane` = the thread's index among the TILE_THREADS that work on this tile: threadIdx.x unless a workgroup holds several tiles)
 __device__ __forceinline__ uint4 tile_fetch(const uint8_t* __restrict__ ab, int64_t lo_valid, int64_t hi_valid, uint64_t tile,
-                                            const uint16_t* __restrict__ pinv = nullptr) {
-    const int64_t g = (int64_t)(tile * TILE_STARTS) - 16 + 16 * (int)threadIdx.x;
+                                            const uint16_t* __restrict__ pinv = nullptr, int lane = -1) {
+    const int64_t g = (int64_t)(tile * TILE_STARTS) - 16 + 16 * (lane < 0 ? (int)threadIdx.x : lane);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (g + 16 > lo_valid && g < hi_valid) {
         if (pinv) { v.x = reinterpret_cast<const uint32_t*>(ab)[g >> 4]; v.y = pinv[g >> 4]; }      // (g is a multiple of 16, >= 0 here)
@@ -377,8 +378,8 @@ __device__ __forceinline__ uint4 tile_fetch(const uint8_t* __restrict__ ab, int6
 }
 // LDS half: convert to the 2-bit code stream + invalid-base bit stream (ends with a barrier)
 __device__ __forceinline__ void tile_store(const uint4& v, int64_t lo_valid, int64_t hi_valid, uint64_t tile,
-                                           uint32_t* s_codes, uint32_t* s_inv, bool packed = false) {
-    const int tid = threadIdx.x;
+                                           uint32_t* s_codes, uint32_t* s_inv, bool packed = false, int lane = -1) {
+    const int tid = lane < 0 ? (int)threadIdx.x : lane;
     const int64_t g = (int64_t)(tile * TILE_STARTS) - 16 + 16 * tid;
     uint32_t codes = 0, inv = 0xFFFFu;
     if (g + 16 > lo_valid && g < hi_valid) {
@@ -410,8 +411,8 @@ __device__ __forceinline__ void tile_load(const uint8_t* __restrict__ ab, int64_
 // prev/next = neighbouring base codes, or 4 when that neighbour is not a base of the same run.
 template <bool ALL, class F>
 __device__ __forceinline__ void lane_scan_core(const uint32_t* s_codes, const uint32_t* s_inv, int64_t lo_valid, uint64_t tile,
-                                               int k, F&& f, uint64_t range_lo = 0, uint64_t range_hi = ~0ull) {
-    const int tid = threadIdx.x;
+                                               int k, F&& f, uint64_t range_lo = 0, uint64_t range_hi = ~0ull, int lane = -1) {
+    const int tid = lane < 0 ? (int)threadIdx.x : lane;
     const bool lane_has_work = tid < TILE_STARTS / 16;
     if (!ALL && !lane_has_work) return;
     const int t = lane_has_work ? tid : 0;
@@ -477,10 +478,10 @@ struct EmitRange { uint64_t lo, hi; };
 // f(i, valid, fw, rv, prev, next) for all 16 starts; starts outside `er` are reported invalid
 template <class F>
 __device__ __forceinline__ void tile_lane_scan_all(const uint32_t* s_codes, const uint32_t* s_inv, int64_t lo_valid, uint64_t tile,
-                                                   int k, EmitRange er, F&& f) {
+                                                   int k, EmitRange er, F&& f, int lane = -1) {
     lane_scan_core<true>(s_codes, s_inv, lo_valid, tile, k,
                          [&](int i, bool valid, uint64_t, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) { f(i, valid, fw, rv, prev, next); },
-                         er.lo, er.hi);
+                         er.lo, er.hi, lane);
 }
 
 // number of valid k-mer starts among this lane's 16

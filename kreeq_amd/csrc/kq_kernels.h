@@ -235,6 +235,99 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
     }
 }
 
+// P1 pass B for narrow records into the 256 hash-prefix buckets, "streamed" formulation: a lane does not hold its 16 records
+// (and their ranks) in registers through the scan -- every scan step counts its record's bin (LDS add without return) and
+// parks the record word in the lane's own column of the stage; after the bin scan the lane takes its 16 words back, and
+// behind a barrier they go to their sorted places IN the same stage (cursor atomics), from where the copy-out runs as in
+// block_multisplit.  The scan's live registers are then the scanner's alone, the stage is the only large LDS array (37 KiB
+// per workgroup: four workgroups per CU instead of three), thread b owns bin b (its absolute cursor stays in a register:
+// five barriers per round instead of seven).  Same count matrix, same cursors, same output as k_p1_scatter<FMT_NARROW>.
+#ifndef KQ_P1S_TPR
+#define KQ_P1S_TPR 2          // tiles per round of an unfiltered scatter (measured: 1 -> 2 takes 22 % off it; a filtered one is faster at 1)
+#endif
+// TPR = tiles per round: TPR x 256 threads, every 256 of them scan one tile (the workgroup's tiles b, b + G, b + 2G, ... taken TPR at a
+// time), ONE split over the TPR x 4032 starts: runs of a bin TPR times as long at the same number of waves per CU.
+template <int BINMODE, int KC, int TPR>
+__global__ __launch_bounds__(TILE_THREADS * TPR, 4 / TPR) void k_p1_scatter_s(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k_arg,
+                                                             PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
+                                                             uint32_t* __restrict__ recs, uint8_t* __restrict__ recs_aux,
+                                                             const uint16_t* __restrict__ pinv /*packed input or null*/) {
+    constexpr uint32_t NB = 1u << NARROW_CBITS;                         // bin NB = "no record"
+    constexpr int THREADS = TILE_THREADS * TPR;
+    static_assert(NB == TILE_THREADS && MS_TILE == TILE_THREADS * 16 && (TPR == 1 || TPR == 2 || TPR == 4), "thread b owns bin b");
+    __shared__ uint32_t s_codes[TPR][TILE_THREADS];
+    __shared__ uint32_t s_inv[TPR][TILE_THREADS];
+    __shared__ uint64_t s_buf[TPR * MS_TILE];
+    __shared__ uint32_t s_hist[NB], s_loff[NB + 1], s_grel[NB], s_wave[TILE_THREADS / 64];
+    const int k = KC ? KC : k_arg;
+    const int tid = threadIdx.x, half = tid / TILE_THREADS, lane = tid % TILE_THREADS;
+    const bool bin_owner = TPR == 1 || tid < (int)NB;
+    const int64_t lo_valid = (int64_t)lead, hi_valid = (int64_t)(lead + len);
+    const uint64_t n_tiles = n_tiles_of(lead, len), stride = (uint64_t)gridDim.x * TPR, mine = (uint64_t)half * gridDim.x;
+    uint32_t gabs = bin_owner ? (uint32_t)m1[(uint64_t)tid * gridDim.x * P1_F + (uint64_t)blockIdx.x * P1_F] : 0u;      // bin tid's output cursor
+    if (bin_owner) s_hist[tid] = 0;
+    uint4 nxt = tile_fetch(ab, lo_valid, hi_valid, blockIdx.x + mine, pinv, lane);      // (a tile behind the last one reads nothing and has no valid start)
+    landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w);
+    for (uint64_t tile0 = blockIdx.x; tile0 < n_tiles; tile0 += stride) {
+        const uint64_t tile = tile0 + mine;
+        tile_store(nxt, lo_valid, hi_valid, tile, s_codes[half], s_inv[half], pinv != nullptr, lane);        // barrier inside (covers the zeroed counters)
+        if (tile0 + stride < n_tiles) nxt = tile_fetch(ab, lo_valid, hi_valid, tile + stride, pinv, lane);    // in flight during the split
+        tile_lane_scan_all(s_codes[half], s_inv[half], lo_valid, tile, k, er, [&](int i, bool valid, uint64_t fw, uint64_t rv, uint32_t prev, uint32_t next) {
+            const bool is_fw = fw < rv;
+            const uint64_t key = is_fw ? fw : rv;
+            const uint64_t h = table_hash(key, (uint32_t)k);
+            const uint32_t b = valid ? p1_bin_of<BINMODE>(cfg, key, h) : NB;
+            if (b != NB) atomicAdd(&s_hist[b], 1u);
+            s_buf[half * MS_TILE + i * TILE_THREADS + lane] = narrow_word(narrow_main(h), narrow_aux(h, edge_idx6_any(is_fw, prev, next)), b);
+        }, lane);
+        __syncthreads();
+        // exclusive scan of the 256 counts: one bin per thread
+        const uint32_t cnt = bin_owner ? s_hist[tid] : 0u;
+        uint32_t incl = cnt;
+        if (bin_owner) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += n; }
+            if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        }
+        uint64_t w[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) w[it] = s_buf[half * MS_TILE + it * TILE_THREADS + lane];            // this lane's own words
+        __syncthreads();
+        if (bin_owner) {
+            uint32_t excl = incl - cnt;
+            for (int v = 0; v < (tid >> 6); ++v) excl += s_wave[v];
+            s_loff[tid] = excl;
+            if (tid == (int)NB - 1) s_loff[NB] = excl + cnt;
+            s_hist[tid] = excl;                                         // the bin's placement cursor
+            s_grel[tid] = gabs - excl;                                  // output index of staged record j of bin tid = s_grel + j
+            gabs += cnt;
+        }
+        __syncthreads();
+        uint32_t pl[16];                                                // (two loops: the sixteen cursor atomics are in flight together)
+#pragma unroll
+        for (int it = 0; it < 16; ++it) { const uint32_t b = narrow_word_bin(w[it]); pl[it] = b != NB ? atomicAdd(&s_hist[b], 1u) : ~0u; }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) if (pl[it] != ~0u) s_buf[pl[it]] = w[it];
+        __syncthreads();
+        const uint32_t total = s_loff[NB];
+        uint64_t cv[16];
+        uint32_t cg[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) cv[it] = s_buf[tid + it * THREADS];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) cg[it] = s_grel[(uint32_t)(tid + it * THREADS) < total ? narrow_word_bin(cv[it]) : 0u] + (tid + it * THREADS);   // (behind `total` the stage holds stale words)
+        if (bin_owner) s_hist[tid] = 0;                                 // (all placements are behind the barrier above)
+        landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w);     // the wait for the prefetch in front of the stores (block_multisplit)
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if ((uint32_t)(tid + it * THREADS) < total) {
+                recs[cg[it]] = (uint32_t)cv[it];
+                recs_aux[cg[it]] = (uint8_t)(cv[it] >> 48);
+            }
+        }
+    }
+}
+
 // ---- one generic level of the record split (LevelCfg) -----------------------------------------
 // work units: segment b is cut into ceil(size_b / P2_UNIT) units; unit_base = exclusive prefix
 // (one workgroup; n_seg <= SEG_MAX: every thread takes a run of consecutive segments, the run totals are scanned)

@@ -85,6 +85,12 @@ __device__ __forceinline__ uint32_t edge_idx6(bool is_fw, uint32_t prev, uint32_
     else       { f = prev < 4 ? 3u - prev : 7u; b = next < 4 ? 3u - next : 7u; }
     return f | (b << 3);
 }
+// the same without selects, for records whose readers only ask "index < 4" (the region kernels' lookup table, k_lookup_regions):
+// "no edge" comes out as 4 (forward strand) or 7 (reverse: 4 ^ 3) instead of always 7.  prev / next in 0..4.
+__device__ __forceinline__ uint32_t edge_idx6_any(bool is_fw, uint32_t prev, uint32_t next) {
+    const uint32_t f = is_fw ? next : prev, b = is_fw ? prev : next, m = is_fw ? 0u : 0x1Bu;      // (three selects: written as one, the compiler branches on the strand)
+    return (f | (b << 3)) ^ m;
+}
 __device__ __forceinline__ uint64_t rec_pack(uint64_t key, bool is_fw, uint32_t prev, uint32_t next) {
     return key | ((uint64_t)edge_idx6(is_fw, prev, next) << REC_EDGE_SHIFT);
 }
@@ -283,7 +289,7 @@ __device__ __forceinline__ void block_multisplit(S& s, const uint64_t (&rec)[ITE
     uint64_t cv[ITEMS];
     if (FMT == FMT_NARROW) {
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) { cv[it] = s.stage[tid + it * THREADS]; cb[it] = tid + it * THREADS < total ? narrow_word_bin(cv[it]) : 0u; }   // (behind `total` the stage holds stale words)
+        for (int it = 0; it < ITEMS; ++it) { cv[it] = s.stage[tid + it * THREADS]; cb[it] = (uint32_t)(tid + it * THREADS) < total ? narrow_word_bin(cv[it]) : 0u; }   // (behind `total` the stage holds stale words)
     } else {
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) { const uint32_t j = tid + it * THREADS; cb[it] = j < total ? s.sbin[j] : 0u; cv[it] = s.stage[j]; }

@@ -789,15 +789,21 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
 #define KQ_P1S(W, N, B, K) hipLaunchKernelGGL((k_p1_scatter<W, N, B, K>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt, pinv)
     if (cfg.narrow && h->k > PART_MAX_K) { if (plain && h->k == 31) KQ_P1S(FMT_TOP8, 512, 2, 31); else if (plain) KQ_P1S(FMT_TOP8, 512, 2, 0); else KQ_P1S(FMT_TOP8, 512, 0, 0); }
-    else if (narrow_filt)  { if (h->k == 21) KQ_P1S(FMT_NARROW, 512, 4, 21); else KQ_P1S(FMT_NARROW, 512, 4, 0); }
-    else if (narrow_win)   { if (h->k == 21) KQ_P1S(FMT_NARROW, 512, 6, 21); else KQ_P1S(FMT_NARROW, 512, 6, 0); }
-    else if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1S(FMT_NARROW, 512, 2, 21); else if (plain) KQ_P1S(FMT_NARROW, 512, 2, 0); else KQ_P1S(FMT_NARROW, 512, 0, 0); }     // 256 buckets
+#ifndef KQ_P1_V1      // narrow records: the streamed scatter (k_p1_scatter_s); a pass that keeps every k-mer splits two tiles per round, a filtered one one
+#define KQ_P1N(B, K, T) hipLaunchKernelGGL((k_p1_scatter_s<B, K, T>), dim3(p->g1), dim3(TILE_THREADS * T), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, (uint32_t*)out, out_aux, pinv)
+#else
+#define KQ_P1N(B, K, T) KQ_P1S(FMT_NARROW, 512, B, K)
+#endif
+    else if (narrow_filt)  { if (h->k == 21) KQ_P1N(4, 21, 1); else KQ_P1N(4, 0, 1); }
+    else if (narrow_win)   { if (h->k == 21) KQ_P1N(6, 21, 1); else KQ_P1N(6, 0, 1); }
+    else if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1N(2, 21, KQ_P1S_TPR); else if (plain) KQ_P1N(2, 0, KQ_P1S_TPR); else KQ_P1N(0, 0, 1); }     // 256 buckets
     else if (out_aux && plain && h->k == 31) { if (small) KQ_P1S(FMT_WIDE, 512, 1, 31); else KQ_P1S(FMT_WIDE, NB_MAX, 1, 31); }   // the HiFi k
     else if (out_aux) { if (small) KQ_P1S(FMT_WIDE, 512, 0, 0); else KQ_P1S(FMT_WIDE, NB_MAX, 0, 0); }
     else if (owner_plain && !out_aux && small) { if (h->k == 21) KQ_P1S(FMT_PACK8, 512, 3, 21); else KQ_P1S(FMT_PACK8, 512, 3, 0); }
     else if (plain)   { if (small) KQ_P1S(FMT_PACK8, 512, 1, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 1, 0); }
     else              { if (small) KQ_P1S(FMT_PACK8, 512, 0, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 0, 0); }
 #undef KQ_P1S
+#undef KQ_P1N
     mark(h, "k_p1_scatter");
 }
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
