@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--slice-kmers", type=int, default=0, help="KQ_OPT_SLICE_KMERS (0 = the library's choice)")
     ap.add_argument("--slice-cap", type=int, default=1 << 31, help="human workload: a batch is cut into equal slices of at most this many k-mer starts")
     ap.add_argument("--no-overlap", action="store_true", help="KQ_OPT_OVERLAP = 0")
+    ap.add_argument("--alt-kernels", default="", help="measurement only: comma-separated KQ_OPT_KERNEL_SET masks, step i runs with mask[i %% n] "
+                    "(previous and shipped kernels timed in one process on the same buffers: read the kernel trace, not `value`)")
     ap.add_argument("--range-by", choices=["map", "bucket"], default="map",
                     help="human workload in several passes: ranges of the reference's maps (key %% 128) or of the table's 256 hash-prefix buckets")
     ap.add_argument("--narrow-mid", type=int, default=0, help="KQ_OPT_NARROW_MID (tuning: regions per bucket from which the record split gets a middle level)")
@@ -283,6 +285,7 @@ def run_human(args, dev, world=1, rank=0):
     # kq_sync).  Between two ranges -- outside the clock, like the final validation -- the finished table is summarised and the
     # assembly is validated against it (counters accumulate over the ranges, src/kreeq.cpp:59-74), then it is cleared.
     dt = dev_ms = t_val = 0.0
+    alt_kernels = [int(x) for x in args.alt_kernels.split(",") if x != ""]
     summ = {"total": 0, "unique": 0, "distinct": 0, "edges": 0}
     c = [0, 0, 0]
     table_passes, passes_before = [], db.info()["table_passes"]        # (the warm-up's pass is not the job's)
@@ -295,6 +298,8 @@ def run_human(args, dev, world=1, rank=0):
         t0 = time.perf_counter()
         ev0.record()
         for i in range(steps):
+            if alt_kernels:
+                db.set_option("kernel_set", alt_kernels[i % len(alt_kernels)])
             count(i)
         db.sync()                        # applies what is still pending: the table is complete when the clock stops
         ev1.record()

@@ -143,8 +143,14 @@ void* kq_get_stream(kq_handle* h);
  *                          that a batch keeps its device address and content between those passes.  The first pass that scans a
  *                          slice then counts its k-mers for all n ranges in one histogram scan and keeps the count matrices (<= 4 GB);
  *                          the other passes skip that scan.  Results never depend on it.  Setting the option drops what is kept. */
+/*   KQ_OPT_KERNEL_SET      measurement only (results never depend on it): bit mask of count-path stages that run their ALTERNATIVE kernel
+ *                          instead of the shipped one, so that both can be timed in one process on the same buffers
+ *                          (tools/bench_extra/alt_kernels.sh, bench.py --alt-kernels): 1 = P1 scatter of narrow records with k_p1_scatter
+ *                          (round 2's) instead of k_p1_scatter_s, 2 = split levels that write narrow records with k_lv_scatter_s (the
+ *                          streamed formulation, which lost there) instead of k_lv_scatter, 4 = the level that writes tight records
+ *                          with k_lv_scatter (round 2's) instead of k_lv_scatter_s.  Default 0. */
 enum { KQ_OPT_TRUST_CAPACITY = 1, KQ_OPT_COUNT_PATH = 2, KQ_OPT_SLICE_KMERS = 3, KQ_OPT_COUNT_MAP_RANGE = 4, KQ_OPT_PROFILE = 5,
-       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8, KQ_OPT_PENDING_BYTES = 9, KQ_OPT_BUCKET_WINDOW = 10, KQ_OPT_OVERLAP = 11, KQ_OPT_COUNT_MAP_PASSES = 12,
+       KQ_OPT_LOOKUP_PATH = 6, KQ_OPT_MERGE_PATH = 7, KQ_OPT_NARROW_MID = 8, KQ_OPT_PENDING_BYTES = 9, KQ_OPT_BUCKET_WINDOW = 10, KQ_OPT_OVERLAP = 11, KQ_OPT_COUNT_MAP_PASSES = 12, KQ_OPT_KERNEL_SET = 13,
        KQ_OPT_TEST_FAIL_PLAN = 100 /* failure-path tests only: the next partition plan of a count fails with KQ_ERR_NOMEM */ };
 int  kq_set_option(kq_handle* h, int option, int64_t value);
 int  kq_get_profile(kq_handle* h, char* buf, uint64_t cap);

@@ -184,7 +184,7 @@ class KreeqDB:
 
     def set_option(self, option, value):
         """option: 'trust_capacity' | 'count_path' ('auto'|'direct'|'partitioned') | 'slice_kmers' | 'count_map_range' ((lo, hi))"""
-        opt = {"trust_capacity": 1, "count_path": 2, "slice_kmers": 3, "count_map_range": 4, "profile": 5, "lookup_path": 6, "merge_path": 7, "narrow_mid": 8, "pending_bytes": 9, "bucket_window": 10, "overlap": 11, "count_map_passes": 12, "test_fail_plan": 100}[option]
+        opt = {"trust_capacity": 1, "count_path": 2, "slice_kmers": 3, "count_map_range": 4, "profile": 5, "lookup_path": 6, "merge_path": 7, "narrow_mid": 8, "pending_bytes": 9, "bucket_window": 10, "overlap": 11, "count_map_passes": 12, "kernel_set": 13, "test_fail_plan": 100}[option]
         if option == "count_map_range":
             value = int(value[0]) | (int(value[1]) << 16)
         if option in ("count_path", "lookup_path", "merge_path"):

@@ -548,6 +548,113 @@ __global__ __launch_bounds__(LV_THREADS, KQ_LV_OCC) void k_lv_scatter(const uint
         }
     }
 }
+// The split level of narrow records in the formulation of k_p1_scatter_s: thread c owns counter c of the (bin, replica) counters
+// (at most 512 = one per thread), the bins' output cursors live in registers of their first counter's thread, the round's counts go
+// to the LDS with adds that return nothing, and every record takes its staged place from a cursor atomic behind the scan -- no rank
+// registers, no cursor arrays, four barriers per round (block_multisplit: six), the counters double-buffered.  TIGHT: the last level,
+// FMT_TIGHT output.  Same units, same count matrix, same output groups as k_lv_scatter<FMT_NARROW / FMT_NARROW_TO_TIGHT, 512>.
+#ifndef KQ_LVS_OCC         // waves per SIMD: two workgroups per CU (at three -- 80 registers, 5 to 9 of them spilled -- the tight level is 8 % slower
+#define KQ_LVS_OCC 4       // than k_lv_scatter instead of 2..8 % faster).  Measured in one process on the same buffers (KQ_OPT_KERNEL_SET): the level
+#define KQ_LVS_OCC_TIGHT 4 // that writes tight records gains (3 Gbp 1.89 -> 1.85 ms, 1 Gbp 3.41 -> 3.15 ms per slice), a level that writes narrow
+#endif                     // records does not (2.03 -> 2.13 / 1.65 -> 1.65 ms, 2.94 -> 3.13 ms): it stays with k_lv_scatter.
+template <bool TIGHT>
+__global__ __launch_bounds__(LV_THREADS, TIGHT ? KQ_LVS_OCC_TIGHT : KQ_LVS_OCC) void k_lv_scatter_s(const uint32_t* __restrict__ recs32, const uint8_t* __restrict__ recs_aux, LevelCfg lv,
+                                                           const unsigned long long* __restrict__ seg_off, const unsigned long long* __restrict__ seg_hi,
+                                                           const unsigned long long* __restrict__ unit_base, const uint32_t* __restrict__ m2,
+                                                           const unsigned long long* __restrict__ group_base, uint32_t* __restrict__ out,
+                                                           uint8_t* __restrict__ out_aux) {
+    constexpr int NC = 512;
+    static_assert(LV_THREADS == NC && LV_ITEMS == 8, "one counter per thread");
+    __shared__ uint64_t s_buf[LV_TILE];
+    __shared__ uint32_t s_hist[2][NC], s_loff[NC + 1], s_grel[NC], s_wave[LV_THREADS / 64];
+    __shared__ uint32_t s_rst[TIGHT ? NC : 1];      // TIGHT (bin = region): rstart[] of the segment's regions
+    const int tid = threadIdx.x;
+    const uint32_t nb = lv.nb, rs = lv.rep_shift, n_ctr = (nb + 1) << rs;      // (nb + 1) << rs <= NC (host)
+    const uint32_t sub = (uint32_t)tid & ((1u << rs) - 1u), my_bin = (uint32_t)tid >> rs;
+    const bool own_bin = sub == 0 && my_bin < nb;                       // this thread's counter is the first of bin my_bin
+    const uint64_t n_units = unit_base[lv.n_seg];
+    for (uint64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint32_t b_in = seg_of_unit(unit_base, lv.n_seg, u);
+        const uint32_t b = lv.spb > 1 ? b_in / lv.spb : b_in;          // logical segment: bin functions and output groups
+        const uint64_t lo = seg_off[b_in] + (u - unit_base[b_in]) * P2_UNIT;
+        const uint64_t hi = lo + P2_UNIT < seg_hi[b_in] ? lo + P2_UNIT : seg_hi[b_in];
+        uint32_t gabs = own_bin ? (uint32_t)(group_base[(uint64_t)b * nb + my_bin] + m2[u * nb + my_bin]) : 0u;      // the bin's output cursor
+        if (TIGHT) {                                                    // (every thread is behind the last barrier of the previous unit: nobody reads s_rst or counts any more)
+            const uint32_t first = (b >> lv.nr_shift) * lv.nr_rps + (b & ((1u << lv.nr_shift) - 1u)) * lv.nr_sub;      // narrow_bin's origin; nr_div == 1
+            if ((uint32_t)tid < nb) s_rst[tid] = lv.rstart[first + tid];
+        }
+        s_hist[0][tid] = 0;
+        __syncthreads();
+        // software pipeline: the next round's records are loaded before this round is split (loads unconditional, index clamped
+        // to the unit: see k_lv_scatter)
+        uint32_t nxt[LV_ITEMS], nxt_aux[LV_ITEMS];
+        const uint64_t last = hi - 1;                                   // a unit is never empty
+#pragma unroll
+        for (int j = 0; j < LV_ITEMS; ++j) {
+            const uint64_t i = min(lo + (uint64_t)j * LV_THREADS + tid, last);
+            nxt[j] = recs32[i];
+            nxt_aux[j] = recs_aux[i];
+        }
+#pragma unroll
+        for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); landed(nxt_aux[j]); }
+        uint32_t par = 0;
+        for (uint64_t pos = lo; pos < hi; pos += LV_TILE, par ^= 1u) {
+            uint32_t* hist = s_hist[par];
+            uint64_t w[LV_ITEMS];
+#pragma unroll
+            for (int j = 0; j < LV_ITEMS; ++j) {
+                const uint64_t i = pos + (uint64_t)j * LV_THREADS + tid;
+                const uint32_t bn = i >= hi ? nb : narrow_bin(lv, b, nxt[j]);
+                w[j] = TIGHT ? narrow_word(tight_rec(b >> lv.nr_shift, nxt[j], nxt_aux[j], s_rst[bn < nb ? bn : 0u]), 0u, bn) : narrow_word(nxt[j], nxt_aux[j], bn);
+                if (bn != nb) atomicAdd(&hist[(bn << rs) | sub], 1u);
+            }
+#pragma unroll
+            for (int j = 0; j < LV_ITEMS; ++j) {
+                const uint64_t i = min(pos + LV_TILE + (uint64_t)j * LV_THREADS + tid, last);
+                nxt[j] = recs32[i];
+                nxt_aux[j] = recs_aux[i];
+            }
+            __syncthreads();
+            // exclusive scan of the counters: one per thread
+            const uint32_t cnt = (uint32_t)tid < n_ctr ? hist[tid] : 0u;
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t n = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += n; }
+            if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+            s_hist[par ^ 1u][tid] = 0;                                  // the next round's counters (last used before the previous round's last barrier)
+            __syncthreads();
+            uint32_t excl = incl - cnt;
+            for (int v = 0; v < (tid >> 6); ++v) excl += s_wave[v];
+            s_loff[tid] = excl;
+            hist[tid] = excl;                                           // the counter's placement cursor
+            if (own_bin) s_grel[my_bin] = gabs - excl;                  // output index of staged record j of the bin = s_grel + j
+            __syncthreads();
+            if (own_bin) gabs += s_loff[(my_bin + 1) << rs] - excl;     // (the first counter of the discard bin holds the total)
+#pragma unroll
+            for (int j = 0; j < LV_ITEMS; ++j) {
+                const uint32_t bn = narrow_word_bin(w[j]);
+                if (bn != nb) s_buf[atomicAdd(&hist[(bn << rs) | sub], 1u)] = w[j];
+            }
+            __syncthreads();
+            const uint32_t total = s_loff[nb << rs];
+            uint64_t cv[LV_ITEMS];
+            uint32_t cg[LV_ITEMS];
+#pragma unroll
+            for (int it = 0; it < LV_ITEMS; ++it) cv[it] = s_buf[tid + it * LV_THREADS];
+#pragma unroll
+            for (int it = 0; it < LV_ITEMS; ++it) cg[it] = s_grel[(uint32_t)(tid + it * LV_THREADS) < total ? narrow_word_bin(cv[it]) : 0u] + (tid + it * LV_THREADS);   // (behind `total`: stale words)
+#pragma unroll
+            for (int j = 0; j < LV_ITEMS; ++j) { landed(nxt[j]); landed(nxt_aux[j]); }      // the wait for the prefetch in front of the stores (block_multisplit)
+#pragma unroll
+            for (int it = 0; it < LV_ITEMS; ++it) {
+                if ((uint32_t)(tid + it * LV_THREADS) < total) {
+                    out[cg[it]] = (uint32_t)cv[it];
+                    if (!TIGHT) out_aux[cg[it]] = (uint8_t)(cv[it] >> 48);
+                }
+            }
+        }
+    }
+}
 __global__ void k_set2(unsigned long long* p, unsigned long long a, unsigned long long b) { p[0] = a; p[1] = b; }
 
 // multi-block exclusive scan helpers (chunks of SCAN_CHUNK elements per workgroup)

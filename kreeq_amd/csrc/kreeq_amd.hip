@@ -91,6 +91,7 @@ struct kq_handle {
     uint64_t ev_next = 0;                            // after the host has seen its previous use complete (ev_get)
     hipEvent_t ev_pass = nullptr;                    // the last table pass on `base` (forked slices write into the arena it read)
     int overlap = 1;                                 // KQ_OPT_OVERLAP
+    int kernel_set = 0;                              // KQ_OPT_KERNEL_SET (measurement only)
     // KQ_OPT_COUNT_MAP_PASSES: count matrices of resident batches, made for all map ranges by the first pass that scans a slice
     struct HistKey { const void* ab; const void* pinv; uint64_t lead, len, er_lo, er_hi; uint32_t g1, n_rng; int k;
                      bool operator==(const HistKey& o) const { return ab == o.ab && pinv == o.pinv && lead == o.lead && len == o.len && er_lo == o.er_lo && er_hi == o.er_hi && g1 == o.g1 && n_rng == o.n_rng && k == o.k; } };
@@ -537,6 +538,9 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             h->hist_cache.clear(); h->hist_cache_bytes = 0;
             h->map_passes = (int)value; return KQ_OK;
         }
+        case KQ_OPT_KERNEL_SET:
+            if (value < 0 || value > 7) return fail(KQ_ERR_INVALID, "KQ_OPT_KERNEL_SET is a mask of bits 1, 2, 4");
+            h->kernel_set = (int)value; return KQ_OK;
         case KQ_OPT_OVERLAP:
             if (value < 0 || value > 2) return fail(KQ_ERR_INVALID, "KQ_OPT_OVERLAP must be 0, 1 or 2");
             h->overlap = (int)value; return KQ_OK;
@@ -789,11 +793,9 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
 #define KQ_P1S(W, N, B, K) hipLaunchKernelGGL((k_p1_scatter<W, N, B, K>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt, pinv)
     if (cfg.narrow && h->k > PART_MAX_K) { if (plain && h->k == 31) KQ_P1S(FMT_TOP8, 512, 2, 31); else if (plain) KQ_P1S(FMT_TOP8, 512, 2, 0); else KQ_P1S(FMT_TOP8, 512, 0, 0); }
-#ifndef KQ_P1_V1      // narrow records: the streamed scatter (k_p1_scatter_s); a pass that keeps every k-mer splits two tiles per round, a filtered one one
-#define KQ_P1N(B, K, T) hipLaunchKernelGGL((k_p1_scatter_s<B, K, T>), dim3(p->g1), dim3(TILE_THREADS * T), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, (uint32_t*)out, out_aux, pinv)
-#else
-#define KQ_P1N(B, K, T) KQ_P1S(FMT_NARROW, 512, B, K)
-#endif
+    // narrow records: the streamed scatter (k_p1_scatter_s); a pass that keeps every k-mer splits two tiles per round, a filtered one one
+#define KQ_P1N(B, K, T) do { if (h->kernel_set & 1) KQ_P1S(FMT_NARROW, 512, B, K); else \
+        hipLaunchKernelGGL((k_p1_scatter_s<B, K, T>), dim3(p->g1), dim3(TILE_THREADS * T), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, (uint32_t*)out, out_aux, pinv); } while (0)
     else if (narrow_filt)  { if (h->k == 21) KQ_P1N(4, 21, 1); else KQ_P1N(4, 0, 1); }
     else if (narrow_win)   { if (h->k == 21) KQ_P1N(6, 21, 1); else KQ_P1N(6, 0, 1); }
     else if (cfg.narrow)   { if (plain && h->k == 21) KQ_P1N(2, 21, KQ_P1S_TPR); else if (plain) KQ_P1N(2, 0, KQ_P1S_TPR); else KQ_P1N(0, 0, 1); }     // 256 buckets
@@ -840,6 +842,12 @@ static void run_level(kq_handle* h, PartPlan* p, const LevelCfg& lv, const uint6
                                         p->seg_off, seg_hi, p->unit_base, p->m2, gb, out, out_aux)
     if (lv.top8)              { KQ_LVS(FMT_PACK8_TO_NARROW, 512); }
     else if (fmt == FMT_TOP8) { if (small) KQ_LVS(FMT_TOP8, 512); else KQ_LVS(FMT_TOP8, NB_MAX); }
+    // narrow records, at most 512 (bin, replica) counters: the streamed scatter (k_lv_scatter_s) for the level that writes tight records
+#define KQ_LVN(T) hipLaunchKernelGGL((k_lv_scatter_s<T>), dim3(unit_grid), dim3(LV_THREADS), 0, h->stream, (const uint32_t*)in, in_aux, lv_, \
+                                      p->seg_off, seg_hi, p->unit_base, p->m2, gb, (uint32_t*)out, out_aux)
+    else if (fmt == FMT_NARROW && small && lv.rstart && !(h->kernel_set & 4)) { KQ_LVN(true); }
+    else if (fmt == FMT_NARROW && small && !lv.rstart && (h->kernel_set & 2)) { KQ_LVN(false); }     // (measured: 0 .. +8 % against k_lv_scatter; not the default)
+#undef KQ_LVN
     else if (fmt == FMT_NARROW && lv.rstart) { if (small) KQ_LVS(FMT_NARROW_TO_TIGHT, 512); else KQ_LVS(FMT_NARROW_TO_TIGHT, NB_MAX); }
     else if (fmt == FMT_NARROW) { if (small) KQ_LVS(FMT_NARROW, 512); else KQ_LVS(FMT_NARROW, NB_MAX); }
     else if (fmt == FMT_WIDE) { if (small) KQ_LVS(FMT_WIDE, 512); else KQ_LVS(FMT_WIDE, NB_MAX); }

@@ -287,3 +287,32 @@ def test_bucket_range_passes(kq, O, n, hint, passes_opt):
         got = got[np.argsort(got["key"])]
         assert H.entries_equal(got, want), cycle
         assert np.array_equal(ctr, c_want)
+
+
+@pytest.mark.parametrize("hint,mid,rng", [(5_000_000, 0, None), (100_000_000, 0, None), (100_000_000, 16, None), (100_000_000, 16, (32, 96))])
+def test_alternative_kernels_give_the_same_table(kq, O, hint, mid, rng):
+    """KQ_OPT_KERNEL_SET (measurement option): every combination of shipped / alternative P1 and level kernels -- narrow records,
+    tight records at 10^8 slots, a middle level (KQ_OPT_NARROW_MID), a map-range filter -- leaves the oracle's table"""
+    cpu = O.OracleDB(21, 128)
+    batches = _batches(3, 21, seed=321)
+    for b in batches:
+        cpu.count_batch(b, threads=8)
+    want = cpu.export()
+    if rng:
+        m = want["key"] % np.uint64(128)
+        want = want[(m >= rng[0]) & (m < rng[1])]
+    for mask in range(8):
+        gpu = kq.KreeqDB(21, 128, capacity_hint=hint)
+        gpu.set_option("count_path", "partitioned")
+        gpu.set_option("trust_capacity", 1)
+        if mid:
+            gpu.set_option("narrow_mid", mid)
+        if rng:
+            gpu.set_option("count_map_range", rng)
+        gpu.set_option("kernel_set", mask)
+        for b in batches:
+            gpu.count_batch(b)
+        assert H.entries_equal(gpu.export(), want), mask
+        gpu.close()
+    with pytest.raises(Exception):
+        kq.KreeqDB(21, 128).set_option("kernel_set", 8)
