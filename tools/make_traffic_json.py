@@ -17,7 +17,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COUNT_KERNELS = ("k_p1_hist", "k_p1_scatter", "k_p1_offsets", "k_lv_units", "k_lv_hist", "k_lv_offsets", "k_lv_scatter", "k_count_regions",
+COUNT_KERNELS = ("k_p1_hist", "k_p1_scatter", "k_p1_scatter_s", "k_p1_offsets", "k_lv_units", "k_lv_hist", "k_lv_offsets", "k_lv_scatter", "k_lv_scatter_s", "k_count_regions",
                  "k_count_regions_n32", "k_count_regions_q4", "k_scan_sums", "k_exclusive_scan", "k_scan_apply", "k_p3set", "k_set2", "k_count_direct")
 
 
