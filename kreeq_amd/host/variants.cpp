@@ -14,12 +14,11 @@
 #include "variants.h"
 
 #include <algorithm>
+#include <chrono>
 #include <deque>
 #include <stdexcept>
 #include <thread>
 #include <tuple>
-#include <unordered_map>
-#include <unordered_set>
 
 namespace kqhost {
 
@@ -51,6 +50,43 @@ uint64_t next_key(uint64_t key, int base, bool fw, int k, bool* is_fw) {
     return hash_kmer(codes, k, is_fw);
 }
 
+// u64 -> T with open addressing (linear probing, power-of-two capacity, grown at load 1/2; no allocation before the first insert).
+// The search never iterates over its maps, so any container with find / insert gives the reference's result; the node-based
+// std::unordered_map cost 0.5 us per cached graph node and as much again to destroy (100 x the HiFi test: 5.7 of 9 s).
+template <class T>
+class FlatMap {
+    std::vector<uint64_t> keys_;
+    std::vector<T> vals_;
+    std::vector<uint8_t> used_;
+    size_t n_ = 0;
+    static size_t mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 29; return (size_t)k; }
+    size_t slot(uint64_t k) const {                                     // the key's slot, or the free slot where it would go
+        size_t i = mix(k) & (keys_.size() - 1);
+        while (used_[i] && keys_[i] != k) i = (i + 1) & (keys_.size() - 1);
+        return i;
+    }
+    void grow() {
+        const size_t cap = keys_.empty() ? 16 : keys_.size() * 2;
+        std::vector<uint64_t> ok(cap); std::vector<T> ov(cap); std::vector<uint8_t> ou(cap, 0);
+        ok.swap(keys_); ov.swap(vals_); ou.swap(used_);
+        for (size_t i = 0; i < ok.size(); ++i) if (ou[i]) { const size_t j = slot(ok[i]); keys_[j] = ok[i]; vals_[j] = std::move(ov[i]); used_[j] = 1; }
+    }
+public:
+    size_t size() const { return n_; }
+    void reserve(size_t n) { while (keys_.size() < 2 * n) grow(); }
+    const T* find(uint64_t k) const { if (keys_.empty()) return nullptr; const size_t i = slot(k); return used_[i] ? &vals_[i] : nullptr; }
+    T* find(uint64_t k) { if (keys_.empty()) return nullptr; const size_t i = slot(k); return used_[i] ? &vals_[i] : nullptr; }
+    bool count(uint64_t k) const { return find(k) != nullptr; }
+    T& operator[](uint64_t k) {                                         // inserts a value-initialised T when absent
+        if (2 * (n_ + 1) > keys_.size()) grow();
+        const size_t i = slot(k);
+        if (!used_[i]) { used_[i] = 1; keys_[i] = k; vals_[i] = T(); ++n_; }
+        return vals_[i];
+    }
+    void clear() { std::fill(used_.begin(), used_.end(), 0); n_ = 0; }
+    void release() { std::vector<uint64_t>().swap(keys_); std::vector<T>().swap(vals_); std::vector<uint8_t>().swap(used_); n_ = 0; }
+};
+
 // The reference's priority queue, include/fibonacci-heap.h, on an index pool.  The search inserts every node except
 // the source with key 0 and its decreaseKey refuses to raise a key (:141), so which of several queued nodes comes out
 // next is decided by the shape of the root list alone: insert links a node left of the minimum (:72-80), extractMin
@@ -58,7 +94,6 @@ uint64_t next_key(uint64_t key, int base, bool fw, int k, bool* is_fw) {
 class NodeQueue {
     struct N { int degree, parent, child, left, right, key; bool mark; uint64_t obj; };
     std::vector<N> n_;
-    std::unordered_map<uint64_t, int> of_;
     std::vector<int> deg_;
     int min_ = -1, count_ = 0;
 
@@ -112,7 +147,6 @@ public:
     void insert(uint64_t obj, int key) {                                 // :57-86
         const int x = (int)n_.size();
         n_.push_back(N{0, -1, -1, x, x, key, false, obj});
-        of_[obj] = x;
         if (min_ >= 0) { const int ml = n_[min_].left; n_[min_].left = x; n_[x].right = min_; n_[x].left = ml; n_[ml].right = x; }
         if (min_ < 0 || n_[min_].key > key) min_ = x;
         ++count_;
@@ -142,11 +176,12 @@ struct Search {
     uint64_t seg_id = 0, c = 0, source = 0, ref = 0;
     bool source_fw = false, has_ref = false;
     std::vector<uint64_t> targets_queue;
-    std::unordered_set<uint64_t> targets;
+    std::vector<uint64_t> targets;                                       // targetsMap: at most maxSpan keys, sorted
+    bool is_target(uint64_t key) const { return std::binary_search(targets.begin(), targets.end(), key); }
     // searchVariants' locals (:173-185)
     NodeQueue Q;
-    std::unordered_map<uint64_t, uint8_t> dist;
-    std::unordered_map<uint64_t, std::pair<uint64_t, bool>> prev;
+    FlatMap<uint8_t> dist;
+    FlatMap<std::pair<uint64_t, bool>> prev;
     std::vector<uint64_t> destinations;
     int depth = 0;
     bool direction = true, started = false, done = false;
@@ -157,7 +192,7 @@ struct Search {
     std::vector<DbgPath> paths;
 };
 
-using Cache = std::unordered_map<uint64_t, Node>;
+using Cache = FlatMap<Node>;
 
 // Runs one search until it needs uncached nodes (their keys are appended to `want`) or is finished.
 void advance(Search& s, const Cache& cache, int k, int kmer_depth, uint32_t cov_cutoff, std::vector<uint64_t>& want) {
@@ -172,9 +207,9 @@ void advance(Search& s, const Cache& cache, int k, int kmer_depth, uint32_t cov_
         if (!s.have_u) {
             if (!(s.Q.size() > 0 && s.depth < kmer_depth + 1)) break;   // :187
             s.u = s.Q.extract_min();                                     // :192
-            auto got = s.prev.find(s.u);                                 // :193-196
-            if (got != s.prev.end()) s.direction = got->second.second;
-            const Node& nu = cache.at(s.u);
+            const auto* got = s.prev.find(s.u);                          // :193-196
+            if (got) s.direction = got->second;
+            const Node& nu = *cache.find(s.u);
             s.cand.clear();
             for (int i = 0; i < 4; ++i) {                                // :232-246
                 if (s.depth == 0) s.direction = s.source_fw;
@@ -191,28 +226,28 @@ void advance(Search& s, const Cache& cache, int k, int kmer_depth, uint32_t cov_
         bool missing = false;
         for (auto& cnd : s.cand) {
             const uint64_t key = std::get<0>(cnd);
-            if (!s.targets.count(key) && !cache.count(key)) { want.push_back(key); missing = true; }
+            if (!s.is_target(key) && !cache.count(key)) { want.push_back(key); missing = true; }
         }
         if (missing) return;                                             // resumed after the batch lookup
         size_t explored_count = 0;
         for (auto& cnd : s.cand) {                                       // :247-260 with checkNext :197-228
             const uint64_t key = std::get<0>(cnd);
             const bool dirn = std::get<2>(cnd), cont = std::get<1>(cnd) ? dirn : !dirn;
-            if (!s.targets.count(key)) {
+            if (!s.is_target(key)) {
                 uint8_t alt = s.dist[s.u];
                 if (alt < 255) ++alt;
                 if (!s.dist.count(key)) { s.dist[key] = 255; s.Q.insert(key, 0); }
                 if (alt < s.dist[key]) { s.prev[key] = std::make_pair(s.u, cont); s.dist[key] = alt; }
             }
             ++explored_count;
-            if (s.targets.count(key)) { s.prev[key] = std::make_pair(s.u, dirn); s.destinations.push_back(key); }
+            if (s.is_target(key)) { s.prev[key] = std::make_pair(s.u, dirn); s.destinations.push_back(key); }
         }
         (void)explored_count;                                            // every candidate is reachable (one map range): edgeCount == exploredCount
         ++s.depth;                                                       // :261
         s.have_u = false;
     }
     // paths from the destinations back to the source (:266-303)
-    auto prev_of = [&](uint64_t key) { auto it = s.prev.find(key); return it == s.prev.end() ? std::make_pair((uint64_t)0, false) : it->second; };
+    auto prev_of = [&](uint64_t key) { const auto* it = s.prev.find(key); return it ? *it : std::make_pair((uint64_t)0, false); };
     for (uint64_t dest : s.destinations) {
         DbgPath path;
         path.pos = s.c + (uint64_t)k;                                    // :139-140
@@ -239,6 +274,9 @@ void advance(Search& s, const Cache& cache, int k, int kmer_depth, uint32_t cov_
         s.paths.push_back(std::move(path));
     }
     s.done = true;
+    // only the paths are read from here on
+    s.dist.release(); s.prev.release(); s.Q = NodeQueue();
+    std::vector<uint64_t>().swap(s.targets_queue); std::vector<uint64_t>().swap(s.targets); std::vector<uint64_t>().swap(s.destinations);
 }
 
 }  // namespace
@@ -303,8 +341,10 @@ std::vector<VariantSite> find_candidate_errors(const GraphSource& g, int k, cons
                         bool erased = false;                             // an occurrence popped at or after the push of t_max
                         const uint64_t from = t_max >= (uint64_t)max_span ? t_max - (uint64_t)max_span + 1 : 0;
                         for (uint64_t t1 = std::max<uint64_t>(from, (uint64_t)k); t1 <= c + k && !erased; ++t1) erased = seg_keys[t1] == key;
-                        if (!erased) s.targets.insert(key);
+                        if (!erased) s.targets.push_back(key);
                     }
+                    std::sort(s.targets.begin(), s.targets.end());
+                    s.targets.erase(std::unique(s.targets.begin(), s.targets.end()), s.targets.end());
                     searches.push_back(std::move(s));
                 }
             }
@@ -312,6 +352,9 @@ std::vector<VariantSite> find_candidate_errors(const GraphSource& g, int k, cons
         }
     }
     if (log) log("Candidate positions after the device pre-filter: " + std::to_string(searches.size()) + " of " + std::to_string(n_pos));
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_adv = 0, t_sort = 0, t_look = 0, t_cache = 0;
+    size_t n_rounds = 0, n_keys = 0;
 
     // 3. lockstep rounds: advance every search, fetch what they ask for in one batch
     Cache cache;
@@ -326,6 +369,7 @@ std::vector<VariantSite> find_candidate_errors(const GraphSource& g, int k, cons
             // the searches of a round are independent (each reads the cache and its own state): a few host threads share
             // them when there are enough (HiFi-scale inputs flag tens of thousands of positions per batch)
             const size_t n_live = hi - lo;
+            double t0 = now();
             unsigned n_thr = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
             if (n_live < 512) n_thr = 1;
             if (n_thr > 1) {
@@ -342,22 +386,29 @@ std::vector<VariantSite> find_candidate_errors(const GraphSource& g, int k, cons
                 for (size_t i = lo; i < hi; ++i) if (!searches[i].done) advance(searches[i], cache, k, kmer_depth, cov_cutoff, want);
             }
             for (size_t i = lo; i < hi && !any; ++i) any = !searches[i].done;
+            t_adv += now() - t0; t0 = now();
             if (!any) break;
             std::sort(want.begin(), want.end());
             want.erase(std::unique(want.begin(), want.end()), want.end());
             if (want.empty()) throw std::runtime_error("candidate-error search stalled");
+            t_sort += now() - t0; t0 = now();
             got.resize(want.size());
             g.lookup(want, got);
+            t_look += now() - t0; t0 = now();
+            cache.reserve(cache.size() + got.size());
             for (auto& e : got) {
-                Node n;
+                Node& n = cache[e.key];
                 for (int w = 0; w < 4; ++w) { n.fw[w] = e.fw[w]; n.bw[w] = e.bw[w]; }
                 n.present = e.cov != 0;
-                cache.emplace(e.key, n);
             }
+            t_cache += now() - t0;
+            ++n_rounds; n_keys += want.size();
         }
         if (cache.size() > (1u << 24)) cache.clear();                    // bounded memory on large assemblies
     }
 
+    if (log) log("Search rounds: " + std::to_string(n_rounds) + ", keys fetched " + std::to_string(n_keys) + "; advance " + std::to_string(t_adv) + " s, sort " + std::to_string(t_sort) +
+                 " s, lookup " + std::to_string(t_look) + " s, cache " + std::to_string(t_cache) + " s");
     // 4. sites in sequence / position order
     std::vector<VariantSite> out;
     for (auto& s : searches) {
