@@ -12,7 +12,7 @@ ctr = torch.zeros(3, dtype=torch.int64, device="cuda")
 pb = torch.zeros(t.numel() * 16, dtype=torch.uint8, device="cuda")
 for path in ("direct", "partitioned"):
   db.set_option("lookup_path", path)
-  for name, seq, per_base in (("reads-as-assembly", t, False), ("genome(1e-4 subst)", ga, False)):
+  for name, seq, per_base in (("reads-as-assembly", t, False), ("genome(1e-4 subst)", ga, False)) + ((("reads-as-assembly per-base", t, True),) if path == "direct" else ()):
       for i in range(2):
           db.lookup_sequence_dev(seq.data_ptr(), seq.numel(), ctr.data_ptr(), per_base_ptr=pb.data_ptr() if per_base else None)
       torch.cuda.synchronize(); ctr.zero_(); torch.cuda.synchronize()
