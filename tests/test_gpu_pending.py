@@ -316,3 +316,29 @@ def test_alternative_kernels_give_the_same_table(kq, O, hint, mid, rng):
         gpu.close()
     with pytest.raises(Exception):
         kq.KreeqDB(21, 128).set_option("kernel_set", 8)
+
+
+@pytest.mark.parametrize("maps,hint,rng", [(100, 5_000_000, None), (100, 100_000_000, (10, 70)), (100, 5_000_000, (0, 37)), (1, 100_000_000, None), (96, 100_000_000, (32, 96))])
+def test_map_counts_other_than_128(kq, O, maps, hint, rng):
+    """the C-ABI takes any map count (the reference fixes 128): key % mapCount without a mask in the filters of the partitioned
+    count (the generic bin function of P1), in export and in the lookup -- against the oracle with the same map count"""
+    gpu, cpu = kq.KreeqDB(21, maps, capacity_hint=hint), O.OracleDB(21, maps)
+    gpu.set_option("count_path", "partitioned")
+    gpu.set_option("trust_capacity", 1)
+    if rng:
+        gpu.set_option("count_map_range", rng)
+    for b in _batches(3, 21, seed=77):
+        gpu.count_batch(b)
+        cpu.count_batch(b, threads=8)
+    want = cpu.export()
+    if rng:
+        m = want["key"] % np.uint64(maps)
+        want = want[(m >= rng[0]) & (m < rng[1])]
+    assert H.entries_equal(gpu.export(), want)
+    _, genome = H.synth_reads(10, 150, 400_000, seed=77)
+    lo, hi = rng if rng else (0, maps)
+    for path in ("direct", "partitioned"):
+        gpu.set_option("lookup_path", path)
+        c_gpu, _ = gpu.lookup_sequence(genome, map_lo=lo, map_hi=hi)
+        c_cpu, _ = cpu.validate_sequence(genome, map_lo=lo, map_hi=hi)
+        assert np.array_equal(c_gpu, c_cpu), path
