@@ -110,6 +110,8 @@ static int scr_ensure(Scrambled& b, size_t need, int device) {
     return KQ_OK;
 }
 
+struct kq_handle;
+static void arena_release(kq_handle* h);
 struct kq_handle {
     int device = 0, k = 0, map_count = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -170,6 +172,7 @@ struct kq_handle {
     // pending record sets (see "pending sets" below): region-sorted records of earlier slices / batches that have not
     // been applied to the table yet; one k_count_regions pass takes them all
     void* arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
+    Scrambled arena_scr;                 // owns `arena` when it is a scrambled buffer (KQ_SCRAMBLE_ARENA)
     P3Set* d_sets = nullptr;             // device array [P3_MAX_SETS]
     int n_pend = 0, pend_fmt = -1, pend_aux_fmt = 0;
     uint64_t pend_records = 0;           // upper bound of the records in the pending sets
@@ -235,6 +238,11 @@ static int grid_for(const kq_handle* h, uint64_t work_items, int per_block, int 
     return (int)blocks;
 }
 
+static void arena_release(kq_handle* h) {
+    if (!h->arena) return;
+    if (h->arena_scr.p) scr_free(h->arena_scr); else (void)hipFree(h->arena);
+    h->arena = nullptr; h->arena_bytes = 0;
+}
 static int ensure_buf(void** p, size_t* have, size_t need) {
     if (*have >= need) return KQ_OK;
     if (*p) { HIPC(hipFree(*p)); *p = nullptr; *have = 0; }
@@ -548,7 +556,7 @@ void kq_destroy(kq_handle* h) {
     for (int i = 0; i < kq_handle::IN_SLOTS; ++i) { if (h->in_buf[i]) (void)hipFree(h->in_buf[i]); if (h->in_consumed[i]) (void)hipEventDestroy(h->in_consumed[i]); }
     for (auto e : h->in_copied) (void)hipEventDestroy(e);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
-    if (h->arena) (void)hipFree(h->arena);
+    arena_release(h);
     if (h->d_sets) (void)hipFree(h->d_sets);
     if (h->hot) (void)hipFree(h->hot);
     marks_reset(h);
@@ -617,7 +625,7 @@ int kq_set_option(kq_handle* h, int option, int64_t value) {
             if (value < -1) return fail(KQ_ERR_INVALID, "KQ_OPT_PENDING_BYTES must be -1 (auto), 0 (off) or a byte count");
             int rc = flush_pending(h);
             if (rc) return rc;
-            if (h->arena && value != h->pend_budget) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
+            if (h->arena && value != h->pend_budget) { HIPC(hipStreamSynchronize(h->stream)); arena_release(h); }
             h->pend_budget = value; return KQ_OK;
         }
         case KQ_OPT_BUCKET_WINDOW:
@@ -1013,7 +1021,10 @@ static int arena_take(kq_handle* h, uint64_t n_max, int fmt, uint64_t R, P3Set* 
         if (budget <= h->arena_bytes && need <= h->arena_bytes) budget = 0;         // at its ceiling already
         if (budget && budget < need) return KQ_OK;
         if (budget) {
-            if (h->arena) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipStreamSynchronize(h->base)); HIPC(hipFree(h->arena)); h->arena = nullptr; h->arena_bytes = 0; }
+            if (h->arena) { HIPC(hipStreamSynchronize(h->stream)); HIPC(hipStreamSynchronize(h->base)); arena_release(h); }
+            static const bool scramble_arena = !getenv("KQ_SCRAMBLE_ARENA") || atoi(getenv("KQ_SCRAMBLE_ARENA")) != 0;      // (0: plain hipMalloc, for A/B)
+            if (scramble_arena && budget >= ((size_t)1 << 30) && scr_try_vmm(h->arena_scr, budget, h->device)) h->arena = h->arena_scr.p;
+            else
             if (hipMalloc(&h->arena, budget) != hipSuccess) { (void)hipGetLastError(); h->arena = nullptr; return KQ_OK; }
             h->arena_bytes = budget; h->arena_used = 0;
         }
