@@ -1264,8 +1264,18 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_n32(Ta
 #ifndef KQ_Q4_PF_TIGHT
 #define KQ_Q4_PF_TIGHT 4       // records per lane and ticket for 4-byte records (one register each): 1000 Mbp 20.2 -> 18.7 ms per step against 2; 5-byte records keep 2 (35 spilled registers at 4, no gain)
 #endif
+// 256 threads, four workgroups per CU (second half of round 3): at 512 x 3 the kernel held 80 VGPRs and spilled 14 of them, and the PMC
+// showed what that costs -- every wave stores and reloads them once per region: 28.7 KB of scratch traffic each way per 32 KB image,
+// 95 of the 203 GB a pass wrote.  With 104 VGPRs nothing spills; the pass is 1 % (3 Gbp) to 5 % (1 Gbp, configs[1]) faster and moves
+// a third fewer bytes.  (Half the threads for the other region kernels was measured too: k = 31 counts 0.75 -> 1.03 ms, union 1.84 ->
+// 2.59 ms -- they keep 512.)
+#ifndef KQ_Q4_THREADS
+#define KQ_Q4_THREADS 256
+#define KQ_Q4_OCC 4
+#endif
+constexpr int Q4_THREADS = KQ_Q4_THREADS;
 template <int KC, bool TIGHT>
-__global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(TableView t, const P3Set* __restrict__ sets, uint32_t n_sets, int table_is_empty,
+__global__ __launch_bounds__(Q4_THREADS, KQ_Q4_OCC) void k_count_regions_q4(TableView t, const P3Set* __restrict__ sets, uint32_t n_sets, int table_is_empty,
                                                                      unsigned long long* __restrict__ hot_list, uint32_t rps) {
     constexpr int PF = TIGHT ? KQ_Q4_PF_TIGHT : KQ_P3_PF;
     constexpr int DEPTH = TIGHT ? KQ_Q4_DEPTH : KQ_Q4_DEPTH_NT;            // tickets a wave has in flight
@@ -1275,7 +1285,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
     __shared__ uint32_t s_cnt[REGION_SLOTS];
     __shared__ uint64_t s_e[REGION_SLOTS];
     __shared__ uint64_t s_lut[64];
-    __shared__ uint64_t s_q[P3_THREADS / 64][QCAP];                     // per-wave queue of records that did not resolve in their home quad: key | idx6 << 32
+    __shared__ uint64_t s_q[Q4_THREADS / 64][QCAP];                     // per-wave queue of records that did not resolve in their home quad: key | idx6 << 32
     uint32_t* s_key = reinterpret_cast<uint32_t*>(s_key2);
     if (threadIdx.x < 64) s_lut[threadIdx.x] = idx6_to_pack(threadIdx.x);     // visible after the first region's barrier
     __shared__ unsigned int s_new, s_kmers, s_grp;
@@ -1298,7 +1308,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
         ulonglong2* gimg = reinterpret_cast<ulonglong2*>(t.slots + (r << REGION_SHIFT));
         if (n_recs == 0) {
             if (table_is_empty == 2)                                    // lazy kq_clear: this launch initialises every region
-                for (int i = tid; i < (int)REGION_SLOTS; i += P3_THREADS) gimg[i] = make_ulonglong2(0ull, 0ull);
+                for (int i = tid; i < (int)REGION_SLOTS; i += Q4_THREADS) gimg[i] = make_ulonglong2(0ull, 0ull);
             continue;
         }
         if (n_recs > 32ull * REGION_SLOTS) {                            // skewed region: the folding kernel takes it
@@ -1310,7 +1320,7 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
         // dependent round trips -- 23 ns per region and pass at 5.3 M regions whatever the number of records)
         // (DEPTH = 2 keeps two tickets per wave in flight: a region's records come as one short piece per pending set, ~170
         // records of each of 30 sets at 3 Gbp, every piece from another place of the arena.  Measured and not the default.)
-        constexpr int NW = P3_THREADS / 64;
+        constexpr int NW = Q4_THREADS / 64;
         uint32_t recA[PF], auxA[PF], recB[PF], auxB[PF];
         uint32_t nA = 0, nB = 0;
         auto fetch = [&](uint32_t g, uint32_t (&rec)[PF], uint32_t (&aux)[PF], uint32_t& n) {
@@ -1340,13 +1350,13 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
             for (int e = 0; e < 8; ++e) s_hccnt[tid][e] = 0;
         }
         if (table_is_empty) {
-            for (int i = tid; i < (int)REGION_SLOTS; i += P3_THREADS) { s_key[i] = N32_EMPTY; s_cnt[i] = 0; s_e[i] = 0; }
+            for (int i = tid; i < (int)REGION_SLOTS; i += Q4_THREADS) { s_key[i] = N32_EMPTY; s_cnt[i] = 0; s_e[i] = 0; }
         } else {
-            ulonglong2 v[REGION_SLOTS / P3_THREADS];
+            ulonglong2 v[REGION_SLOTS / Q4_THREADS];
 #pragma unroll
-            for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) v[j] = gimg[tid + j * P3_THREADS];
+            for (int j = 0; j < (int)(REGION_SLOTS / Q4_THREADS); ++j) v[j] = gimg[tid + j * Q4_THREADS];
 #pragma unroll
-            for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) {
+            for (int j = 0; j < (int)(REGION_SLOTS / Q4_THREADS); ++j) {
                 const uint64_t w0 = v[j].x;                             // rem56 | cov8 << 56, rem = hash >> 8
                 uint32_t key = N32_EMPTY, cnt = 0;
                 if (w0) {
@@ -1354,12 +1364,12 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
                     const uint32_t c = (uint32_t)(w0 >> COV_SHIFT);
                     cnt = c == COV8_TOMB ? (N32_TOMB | LOW_TIER_MAX) : c;
                 }
-                s_key[tid + j * P3_THREADS] = key;
-                s_cnt[tid + j * P3_THREADS] = cnt;
-                s_e[tid + j * P3_THREADS] = v[j].y;
+                s_key[tid + j * Q4_THREADS] = key;
+                s_cnt[tid + j * Q4_THREADS] = cnt;
+                s_e[tid + j * Q4_THREADS] = v[j].y;
             }
         }
-        if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = DEPTH * (P3_THREADS / 64); }
+        if (tid == 0) { s_new = 0; s_kmers = 0; s_grp = DEPTH * (Q4_THREADS / 64); }
         __syncthreads();
         KQ_STAMP(1);                                                    // first fetch issued, image init / load, barrier
         uint32_t n_new = 0, n_ok = 0;
@@ -1510,8 +1520,8 @@ __global__ __launch_bounds__(P3_THREADS, KQ_N32_OCC) void k_count_regions_q4(Tab
             }
         }
 #pragma unroll
-        for (int j = 0; j < (int)(REGION_SLOTS / P3_THREADS); ++j) {
-            const int i = tid + j * P3_THREADS;
+        for (int j = 0; j < (int)(REGION_SLOTS / Q4_THREADS); ++j) {
+            const int i = tid + j * Q4_THREADS;
             const uint32_t key = s_key[i];
             ulonglong2 o = make_ulonglong2(0ull, 0ull);
             if (key != N32_EMPTY) {

@@ -1100,7 +1100,7 @@ static int flush_pending_base(kq_handle* h) {
 #ifdef KQ_P3_V1       // A/B build: round 2's loop formulation
 #define KQ_N32(KC, T) hipLaunchKernelGGL((k_count_regions_n32<KC, T>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps)
 #else
-#define KQ_N32(KC, T) hipLaunchKernelGGL((k_count_regions_q4<KC, T>), grid, block, 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps)
+#define KQ_N32(KC, T) hipLaunchKernelGGL((k_count_regions_q4<KC, T>), grid, dim3(Q4_THREADS), 0, h->stream, h->view(), h->d_sets, (uint32_t)h->n_pend, empty, hot, rps)
 #endif
         if (fmt == FMT_TIGHT) { if (h->k == 21) KQ_N32(21, true); else KQ_N32(0, true); }
         else                  { if (h->k == 21) KQ_N32(21, false); else KQ_N32(0, false); }
