@@ -247,17 +247,20 @@ __global__ __launch_bounds__(TILE_THREADS, (NBC <= 512 && FMT != FMT_WIDE) ? 3 :
 #endif
 // TPR = tiles per round: TPR x 256 threads, every 256 of them scan one tile (the workgroup's tiles b, b + G, b + 2G, ... taken TPR at a
 // time), ONE split over the TPR x 4032 starts: runs of a bin TPR times as long at the same number of waves per CU.
-template <int BINMODE, int KC, int TPR>
-__global__ __launch_bounds__(TILE_THREADS * TPR, 4 / TPR) void k_p1_scatter_s(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k_arg,
+// TOP8 (k = 29..32): the record is a whole u64 (top8_rec), so its bin travels in a second LDS array (u16) and the stage takes 40 KiB:
+// three workgroups per CU, one tile per round.  Replaces k_p1_scatter<FMT_TOP8> (32 spilled registers at k = 31).
+template <int BINMODE, int KC, int TPR, bool TOP8 = false>
+__global__ __launch_bounds__(TILE_THREADS * TPR, TOP8 ? 3 : 4 / TPR) void k_p1_scatter_s(const uint8_t* __restrict__ ab, uint64_t lead, uint64_t len, int k_arg,
                                                              PartCfg cfg, EmitRange er, const unsigned long long* __restrict__ m1,
-                                                             uint32_t* __restrict__ recs, uint8_t* __restrict__ recs_aux,
+                                                             uint32_t* __restrict__ recs /*TOP8: u64 records*/, uint8_t* __restrict__ recs_aux,
                                                              const uint16_t* __restrict__ pinv /*packed input or null*/) {
     constexpr uint32_t NB = 1u << NARROW_CBITS;                         // bin NB = "no record"
     constexpr int THREADS = TILE_THREADS * TPR;
-    static_assert(NB == TILE_THREADS && MS_TILE == TILE_THREADS * 16 && (TPR == 1 || TPR == 2 || TPR == 4), "thread b owns bin b");
+    static_assert(NB == TILE_THREADS && MS_TILE == TILE_THREADS * 16 && (TPR == 1 || TPR == 2 || TPR == 4) && (!TOP8 || TPR == 1), "thread b owns bin b");
     __shared__ uint32_t s_codes[TPR][TILE_THREADS];
     __shared__ uint32_t s_inv[TPR][TILE_THREADS];
     __shared__ uint64_t s_buf[TPR * MS_TILE];
+    __shared__ uint16_t s_bin[TOP8 ? MS_TILE : 1];
     __shared__ uint32_t s_hist[NB], s_loff[NB + 1], s_grel[NB], s_wave[TILE_THREADS / 64];
     const int k = KC ? KC : k_arg;
     const int tid = threadIdx.x, half = tid / TILE_THREADS, lane = tid % TILE_THREADS;
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(TILE_THREADS * TPR, 4 / TPR) void k_p1_scatter_s(co
             const uint64_t h = table_hash(key, (uint32_t)k);
             const uint32_t b = valid ? p1_bin_of<BINMODE>(cfg, key, h) : NB;
             if (b != NB) atomicAdd(&s_hist[b], 1u);
-            s_buf[half * MS_TILE + i * TILE_THREADS + lane] = narrow_word(narrow_main(h), narrow_aux(h, edge_idx6_any(is_fw, prev, next)), b);
+            if (TOP8) { s_buf[i * TILE_THREADS + lane] = top8_rec(h, edge_idx6_any(is_fw, prev, next)); s_bin[i * TILE_THREADS + lane] = (uint16_t)b; }
+            else s_buf[half * MS_TILE + i * TILE_THREADS + lane] = narrow_word(narrow_main(h), narrow_aux(h, edge_idx6_any(is_fw, prev, next)), b);
         }, lane);
         __syncthreads();
         // exclusive scan of the 256 counts: one bin per thread
@@ -290,8 +294,9 @@ __global__ __launch_bounds__(TILE_THREADS * TPR, 4 / TPR) void k_p1_scatter_s(co
             if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
         }
         uint64_t w[16];
+        uint32_t wb[TOP8 ? 16 : 1];
 #pragma unroll
-        for (int it = 0; it < 16; ++it) w[it] = s_buf[half * MS_TILE + it * TILE_THREADS + lane];            // this lane's own words
+        for (int it = 0; it < 16; ++it) { w[it] = s_buf[half * MS_TILE + it * TILE_THREADS + lane]; if (TOP8) wb[it] = s_bin[it * TILE_THREADS + lane]; }            // this lane's own words
         __syncthreads();
         if (bin_owner) {
             uint32_t excl = incl - cnt;
@@ -305,9 +310,9 @@ __global__ __launch_bounds__(TILE_THREADS * TPR, 4 / TPR) void k_p1_scatter_s(co
         __syncthreads();
         uint32_t pl[16];                                                // (two loops: the sixteen cursor atomics are in flight together)
 #pragma unroll
-        for (int it = 0; it < 16; ++it) { const uint32_t b = narrow_word_bin(w[it]); pl[it] = b != NB ? atomicAdd(&s_hist[b], 1u) : ~0u; }
+        for (int it = 0; it < 16; ++it) { const uint32_t b = TOP8 ? wb[TOP8 ? it : 0] : narrow_word_bin(w[it]); pl[it] = b != NB ? atomicAdd(&s_hist[b], 1u) : ~0u; }
 #pragma unroll
-        for (int it = 0; it < 16; ++it) if (pl[it] != ~0u) s_buf[pl[it]] = w[it];
+        for (int it = 0; it < 16; ++it) if (pl[it] != ~0u) { s_buf[pl[it]] = w[it]; if (TOP8) s_bin[pl[it]] = (uint16_t)wb[TOP8 ? it : 0]; }
         __syncthreads();
         const uint32_t total = s_loff[NB];
         uint64_t cv[16];
@@ -315,14 +320,14 @@ __global__ __launch_bounds__(TILE_THREADS * TPR, 4 / TPR) void k_p1_scatter_s(co
 #pragma unroll
         for (int it = 0; it < 16; ++it) cv[it] = s_buf[tid + it * THREADS];
 #pragma unroll
-        for (int it = 0; it < 16; ++it) cg[it] = s_grel[(uint32_t)(tid + it * THREADS) < total ? narrow_word_bin(cv[it]) : 0u] + (tid + it * THREADS);   // (behind `total` the stage holds stale words)
+        for (int it = 0; it < 16; ++it) cg[it] = s_grel[(uint32_t)(tid + it * THREADS) < total ? (TOP8 ? (uint32_t)s_bin[TOP8 ? tid + it * THREADS : 0] : narrow_word_bin(cv[it])) : 0u] + (tid + it * THREADS);   // (behind `total` the stage holds stale words)
         if (bin_owner) s_hist[tid] = 0;                                 // (all placements are behind the barrier above)
         landed(nxt.x); landed(nxt.y); landed(nxt.z); landed(nxt.w);     // the wait for the prefetch in front of the stores (block_multisplit)
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             if ((uint32_t)(tid + it * THREADS) < total) {
-                recs[cg[it]] = (uint32_t)cv[it];
-                recs_aux[cg[it]] = (uint8_t)(cv[it] >> 48);
+                if (TOP8) reinterpret_cast<uint64_t*>(recs)[cg[it]] = cv[it];
+                else { recs[cg[it]] = (uint32_t)cv[it]; recs_aux[cg[it]] = (uint8_t)(cv[it] >> 48); }
             }
         }
     }

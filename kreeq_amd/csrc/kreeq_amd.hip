@@ -873,7 +873,9 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     mark(h, "k_p1_hist+scan");
     const bool small = cfg.n_coarse < 512;                     // 48 KiB LDS variant: three workgroups per CU
 #define KQ_P1S(W, N, B, K) hipLaunchKernelGGL((k_p1_scatter<W, N, B, K>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, out, out_aux, aux_fmt, pinv)
-    if (cfg.narrow && h->k > PART_MAX_K) { if (plain && h->k == 31) KQ_P1S(FMT_TOP8, 512, 2, 31); else if (plain) KQ_P1S(FMT_TOP8, 512, 2, 0); else KQ_P1S(FMT_TOP8, 512, 0, 0); }
+#define KQ_P1T(B, K) do { if (h->kernel_set & 1) KQ_P1S(FMT_TOP8, 512, B, K); else \
+        hipLaunchKernelGGL((k_p1_scatter_s<B, K, 1, true>), dim3(p->g1), dim3(TILE_THREADS), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, (uint32_t*)out, out_aux, pinv); } while (0)
+    if (cfg.narrow && h->k > PART_MAX_K) { if (plain && h->k == 31) KQ_P1T(2, 31); else if (plain) KQ_P1T(2, 0); else KQ_P1T(0, 0); }
     // narrow records: the streamed scatter (k_p1_scatter_s); a pass that keeps every k-mer splits two tiles per round, a filtered one one
 #define KQ_P1N(B, K, T) do { if (h->kernel_set & 1) KQ_P1S(FMT_NARROW, 512, B, K); else \
         hipLaunchKernelGGL((k_p1_scatter_s<B, K, T>), dim3(p->g1), dim3(TILE_THREADS * T), 0, h->stream, ab, lead, len, h->k, cfg, er, p->m1, (uint32_t*)out, out_aux, pinv); } while (0)
@@ -887,6 +889,7 @@ static void run_p1(kq_handle* h, PartPlan* p, const PartCfg& cfg, const uint8_t*
     else              { if (small) KQ_P1S(FMT_PACK8, 512, 0, 0); else KQ_P1S(FMT_PACK8, NB_MAX, 0, 0); }
 #undef KQ_P1S
 #undef KQ_P1N
+#undef KQ_P1T
     mark(h, "k_p1_scatter");
 }
 // one generic split level: in (grouped by p->seg_off[0..n_seg]) -> out grouped by (segment, bin);
