@@ -145,7 +145,7 @@ void* kq_get_stream(kq_handle* h);
  *                          the other passes skip that scan.  Results never depend on it.  Setting the option drops what is kept. */
 /*   KQ_OPT_KERNEL_SET      measurement only (results never depend on it): bit mask of count-path stages that run their ALTERNATIVE kernel
  *                          instead of the shipped one, so that both can be timed in one process on the same buffers
- *                          (tools/bench_extra/alt_kernels.sh, bench.py --alt-kernels): 1 = P1 scatter of narrow records with k_p1_scatter
+ *                          (tools/bench_extra/alt_kernels.sh, bench.py --alt-kernels): 1 = P1 scatter of narrow and hash-remainder records with k_p1_scatter
  *                          (round 2's) instead of k_p1_scatter_s, 2 = split levels that write narrow records with k_lv_scatter_s (the
  *                          streamed formulation, which lost there) instead of k_lv_scatter, 4 = the level that writes tight records
  *                          with k_lv_scatter (round 2's) instead of k_lv_scatter_s.  Default 0. */

@@ -342,3 +342,22 @@ def test_map_counts_other_than_128(kq, O, maps, hint, rng):
         c_gpu, _ = gpu.lookup_sequence(genome, map_lo=lo, map_hi=hi)
         c_cpu, _ = cpu.validate_sequence(genome, map_lo=lo, map_hi=hi)
         assert np.array_equal(c_gpu, c_cpu), path
+
+
+@pytest.mark.parametrize("hint", [5_000_000, 100_000_000])
+def test_alternative_p1_kernel_k31(kq, O, hint):
+    """k = 31 (hash-remainder records): the streamed P1 scatter and round 2's (KQ_OPT_KERNEL_SET bit 1) leave the oracle's table"""
+    cpu = O.OracleDB(31, 128)
+    batches = _batches(3, 31, seed=131)
+    for b in batches:
+        cpu.count_batch(b, threads=8)
+    want = cpu.export()
+    for mask in (0, 1):
+        gpu = kq.KreeqDB(31, 128, capacity_hint=hint)
+        gpu.set_option("count_path", "partitioned")
+        gpu.set_option("trust_capacity", 1)
+        gpu.set_option("kernel_set", mask)
+        for b in batches:
+            gpu.count_batch(b)
+        assert H.entries_equal(gpu.export(), want), mask
+        gpu.close()
